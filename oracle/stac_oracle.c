@@ -1,0 +1,610 @@
+/*
+ * stac_oracle.c -- CPU restatement of the STAC hot path (see stac_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: never linked into or called from the product path.
+ * Parity status: FK + m_opt pinned; q_phase "PARITY UNPINNED" (see header).
+ *
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).  Compiling with
+ * -DORC_REAL=double gives a float64 twin used by tests for finite-difference and
+ * rounding-sensitivity checks (same symbols, separate .so).
+ */
+#include "stac_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef ORC_REAL
+#define ORC_REAL float
+#endif
+typedef ORC_REAL real;
+
+/* The public ABI is float32; the float64 twin converts at the boundary. */
+#define R(x) ((real)(x))
+
+static inline real rsqrt_(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
+
+/* sin/cos of the hinge half-angle.  The float32 build uses its own Cody-Waite + minimax
+ * polynomial (cephes sinf/cosf coefficients) written with plain mul/add only, so that the HIP
+ * kernels -- which contain the same operation sequence -- reproduce it bit for bit (libm's and
+ * OCML's sinf differ in the last ulp).  Max error ~1.5 ulp for |a| < 100. */
+static inline void sincos_(real a, real *sn, real *cs) {
+    if (sizeof(real) != 4) { *sn = (real)sin((double)a); *cs = (real)cos((double)a); return; }
+    const float x = (float)a;
+    const float k = rintf(x * 0.636619772367581343f);            /* x * 2/pi, round-half-even */
+    float r = x - k * 1.5703125f;                                 /* pi/2 split in three */
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    const float s0 = r + r * z * ps;
+    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float c0 = (1.0f - 0.5f * z) + z * z * pc;
+    const int q = ((int)k) & 3;
+    const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    *sn = (real)((q & 2) ? -ss : ss);
+    *cs = (real)(((q + 1) & 2) ? -cc : cc);
+}
+
+/* ---- mujoco.mjx._src.math restated ------------------------------------- */
+static inline real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(const real *a, const real *b, real *r) {
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* rotate(vec, quat): r = 2(u.v)u + (s^2 - u.u)v + 2 s (u x v) */
+static inline void rotate(const real *v, const real *q, real *r) {
+    const real s = q[0];
+    const real *u = q + 1;
+    real c[3];
+    const real uv = dot3(u, v), uu = dot3(u, u);
+    cross3(u, v, c);
+    for (int i = 0; i < 3; ++i) {
+        real t = R(2) * (uv * u[i]) + (s * s - uu) * v[i];
+        r[i] = t + R(2) * s * c[i];
+    }
+}
+static inline void qmul(const real *u, const real *v, real *r) {
+    real t[4];
+    t[0] = u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3];
+    t[1] = u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2];
+    t[2] = u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1];
+    t[3] = u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0];
+    r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+}
+/* normalize(x) = x / (|x| + 1e-6 [|x| == 0]); returns |x| */
+static inline real normalize4(real *q) {
+    real n = rsqrt_(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    real d = n + (n == R(0) ? R(1e-6) : R(0));
+    for (int i = 0; i < 4; ++i) q[i] = q[i] / d;
+    return n;
+}
+static inline void quat_to_mat(const real *q, real *m /* row-major 3x3 */) {
+    const real q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+    const real q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+    const real q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+    m[0] = q00 + q11 - q22 - q33; m[1] = R(2) * (q12 - q03);      m[2] = R(2) * (q13 + q02);
+    m[3] = R(2) * (q12 + q03);    m[4] = q00 - q11 + q22 - q33;   m[5] = R(2) * (q23 - q01);
+    m[6] = R(2) * (q13 - q02);    m[7] = R(2) * (q23 + q01);      m[8] = q00 - q11 - q22 + q33;
+}
+
+/* ---- workspace ------------------------------------------------------------------------- */
+typedef struct {
+    real *mp;                               /* model tables converted to `real` */
+    real *body_pos, *body_quat, *jnt_pos, *jnt_axis, *qpos0, *site_pos;
+    real *qf, *xpos, *xquat, *xanchor, *xaxis, *jprequat, *jnorm, *sx, *F, *Tq;
+    real *x, *y, *g, *cand, *xn, *gn, *tmp, *kp, *q0, *lb, *ub;
+} ws_t;
+
+static ws_t *ws_new(const orc_model *m) {
+    ws_t *w = (ws_t *)calloc(1, sizeof(ws_t));
+    const int nb = m->nbody, nj = m->njnt, nq = m->nq, K = m->nsite;
+    size_t n_model = (size_t)nb * 7 + (size_t)nj * 6 + nq + (size_t)K * 3;
+    size_t n_fk = (size_t)nq + nb * 7 + nj * 6 + nj * 4 + nj + K * 3 + nb * 6;
+    size_t n_pg = (size_t)nq * 10 + K * 3;
+    real *p = (real *)calloc(n_model + n_fk + n_pg + 64, sizeof(real));
+    w->mp = p;
+    w->body_pos = p; p += nb * 3;
+    w->body_quat = p; p += nb * 4;
+    w->jnt_pos = p; p += nj * 3;
+    w->jnt_axis = p; p += nj * 3;
+    w->qpos0 = p; p += nq;
+    w->site_pos = p; p += K * 3;
+    for (int i = 0; i < nb * 3; ++i) w->body_pos[i] = R(m->body_pos[i]);
+    for (int i = 0; i < nb * 4; ++i) w->body_quat[i] = R(m->body_quat[i]);
+    for (int i = 0; i < nj * 3; ++i) w->jnt_pos[i] = R(m->jnt_pos[i]);
+    for (int i = 0; i < nj * 3; ++i) w->jnt_axis[i] = R(m->jnt_axis[i]);
+    for (int i = 0; i < nq; ++i) w->qpos0[i] = R(m->qpos0[i]);
+    for (int i = 0; i < K * 3; ++i) w->site_pos[i] = R(m->site_pos[i]);
+    w->qf = p; p += nq;
+    w->xpos = p; p += nb * 3;
+    w->xquat = p; p += nb * 4;
+    w->xanchor = p; p += nj * 3;
+    w->xaxis = p; p += nj * 3;
+    w->jprequat = p; p += nj * 4;
+    w->jnorm = p; p += nj;
+    w->sx = p; p += K * 3;
+    w->F = p; p += nb * 3;
+    w->Tq = p; p += nb * 3;
+    w->x = p; p += nq; w->y = p; p += nq; w->g = p; p += nq; w->cand = p; p += nq;
+    w->xn = p; p += nq; w->gn = p; p += nq; w->tmp = p; p += nq; w->q0 = p; p += nq;
+    w->lb = p; p += nq; w->ub = p; p += nq;
+    w->kp = p; p += K * 3;
+    return w;
+}
+static void ws_free(ws_t *w) {
+    if (w) { free(w->mp); free(w); }
+}
+
+/* ---- forward kinematics (mjx smooth.kinematics) ---------------------------- */
+static void fk_ws(const orc_model *m, ws_t *w, real *qpos) {
+    const int nb = m->nbody;
+    real *xpos = w->xpos, *xquat = w->xquat;
+    xpos[0] = xpos[1] = xpos[2] = R(0);
+    xquat[0] = R(1); xquat[1] = xquat[2] = xquat[3] = R(0);
+    for (int b = 1; b < nb; ++b) {
+        const int p = m->body_parentid[b];
+        real pos[3], quat[4], r[3];
+        /* pos = xpos[p] + rotate(body_pos, xquat[p]); quat = xquat[p] * body_quat */
+        rotate(w->body_pos + 3 * b, xquat + 4 * p, r);
+        for (int i = 0; i < 3; ++i) pos[i] = xpos[3 * p + i] + r[i];
+        qmul(xquat + 4 * p, w->body_quat + 4 * b, quat);
+        const int j0 = m->body_jntadr[b], nj = m->body_jntnum[b];
+        for (int j = j0; j < j0 + nj; ++j) {
+            const int a = m->jnt_qposadr[j];
+            real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
+            const real *jpos = w->jnt_pos + 3 * j, *jax = w->jnt_axis + 3 * j;
+            for (int i = 0; i < 4; ++i) w->jprequat[4 * j + i] = quat[i];
+            w->jnorm[j] = R(1);
+            switch (m->jnt_type[j]) {
+            case ORC_JNT_FREE:
+                for (int i = 0; i < 3; ++i) { anchor[i] = qpos[a + i]; pos[i] = qpos[a + i]; }
+                axis[0] = R(0); axis[1] = R(0); axis[2] = R(1);
+                w->jnorm[j] = normalize4(qpos + a + 3); /* written back, like MJX */
+                for (int i = 0; i < 4; ++i) quat[i] = qpos[a + 3 + i];
+                break;
+            case ORC_JNT_BALL: {
+                rotate(jpos, quat, r);
+                for (int i = 0; i < 3; ++i) anchor[i] = r[i] + pos[i];
+                rotate(jax, quat, axis);
+                w->jnorm[j] = normalize4(qpos + a);
+                qmul(quat, qpos + a, quat);
+                rotate(jpos, quat, r);
+                for (int i = 0; i < 3; ++i) pos[i] = anchor[i] - r[i];
+            } break;
+            case ORC_JNT_HINGE: {
+                rotate(jpos, quat, r);
+                for (int i = 0; i < 3; ++i) anchor[i] = r[i] + pos[i];
+                rotate(jax, quat, axis);
+                const real angle = qpos[a] - w->qpos0[a];
+                real s, c;
+                sincos_(angle * R(0.5), &s, &c);
+                real qloc[4] = {c, jax[0] * s, jax[1] * s, jax[2] * s};
+                qmul(quat, qloc, quat);
+                rotate(jpos, quat, r);
+                for (int i = 0; i < 3; ++i) pos[i] = anchor[i] - r[i];
+            } break;
+            case ORC_JNT_SLIDE: {
+                rotate(jpos, quat, r);
+                for (int i = 0; i < 3; ++i) anchor[i] = r[i] + pos[i];
+                rotate(jax, quat, axis);
+                const real d = qpos[a] - w->qpos0[a];
+                for (int i = 0; i < 3; ++i) pos[i] += axis[i] * d;
+            } break;
+            default: break;
+            }
+        }
+        for (int i = 0; i < 3; ++i) xpos[3 * b + i] = pos[i];
+        for (int i = 0; i < 4; ++i) xquat[4 * b + i] = quat[i];
+    }
+    for (int k = 0; k < m->nsite; ++k) {
+        const int b = m->site_bodyid[k];
+        real r[3];
+        rotate(w->site_pos + 3 * k, xquat + 4 * b, r);
+        for (int i = 0; i < 3; ++i) w->sx[3 * k + i] = xpos[3 * b + i] + r[i];
+    }
+}
+
+void orc_fk(const orc_model *m, float *qpos, float *xpos, float *xquat, float *xanchor,
+            float *xaxis, float *site_xpos) {
+    ws_t *w = ws_new(m);
+    for (int i = 0; i < m->nq; ++i) w->qf[i] = R(qpos[i]);
+    fk_ws(m, w, w->qf);
+    for (int i = 0; i < m->nq; ++i) qpos[i] = (float)w->qf[i];
+    if (xpos) for (int i = 0; i < m->nbody * 3; ++i) xpos[i] = (float)w->xpos[i];
+    if (xquat) for (int i = 0; i < m->nbody * 4; ++i) xquat[i] = (float)w->xquat[i];
+    if (xanchor) for (int i = 0; i < m->njnt * 3; ++i) xanchor[i] = (float)w->xanchor[i];
+    if (xaxis) for (int i = 0; i < m->njnt * 3; ++i) xaxis[i] = (float)w->xaxis[i];
+    if (site_xpos) for (int i = 0; i < m->nsite * 3; ++i) site_xpos[i] = (float)w->sx[i];
+    ws_free(w);
+}
+
+/* ---- q_loss and its analytic gradient (stac_core.py:27-63) --------------- */
+static real q_loss_ws(const orc_model *m, ws_t *w, const real *q, const real *kp,
+                      const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const real *initial_q,
+                      real *grad) {
+    const int nq = m->nq, K = m->nsite, nb = m->nbody;
+    /* make_qs (utils.py:129-144): (1 - mask) * q0 + mask * q */
+    for (int i = 0; i < nq; ++i) {
+        const real mi = qs_to_opt[i] ? R(1) : R(0);
+        w->qf[i] = (R(1) - mi) * initial_q[i] + mi * q[i];
+    }
+    fk_ws(m, w, w->qf);
+    /* residual = (kp - markers) * kps_to_opt; loss = sum(residual^2)  (stac_core.py:57-61) */
+    /* summation order: per site (rx^2 + ry^2) + rz^2, then sites in index order (XLA's reduce
+     * order is unspecified; this is the order the HIP kernels reproduce exactly). */
+    real loss = R(0);
+    for (int k = 0; k < K; ++k) {
+        real r[3];
+        for (int i = 0; i < 3; ++i) {
+            const real wi = kps_to_opt[3 * k + i] ? R(1) : R(0);
+            r[i] = (kp[3 * k + i] - w->sx[3 * k + i]) * wi;
+        }
+        loss += (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+    }
+    if (!grad) return loss;
+
+    /* dL/dx_k = -2 w (kp - x_k).  Subtree wrench sums about c = xpos[1] (root body). */
+    const real *c = w->xpos + 3;
+    memset(w->F, 0, sizeof(real) * nb * 3);
+    memset(w->Tq, 0, sizeof(real) * nb * 3);
+    for (int k = 0; k < K; ++k) {
+        const int b = m->site_bodyid[k];
+        real f[3], d[3], t[3];
+        for (int i = 0; i < 3; ++i) {
+            const real wi = kps_to_opt[3 * k + i] ? R(1) : R(0);
+            f[i] = R(-2) * ((kp[3 * k + i] - w->sx[3 * k + i]) * wi);
+            d[i] = w->sx[3 * k + i] - c[i];
+        }
+        cross3(d, f, t);
+        for (int i = 0; i < 3; ++i) { w->F[3 * b + i] += f[i]; w->Tq[3 * b + i] += t[i]; }
+    }
+    for (int b = nb - 1; b >= 1; --b) { /* children have larger ids than parents (DFS order) */
+        const int p = m->body_parentid[b];
+        for (int i = 0; i < 3; ++i) { w->F[3 * p + i] += w->F[3 * b + i]; w->Tq[3 * p + i] += w->Tq[3 * b + i]; }
+    }
+    for (int i = 0; i < nq; ++i) grad[i] = R(0);
+    for (int j = 0; j < m->njnt; ++j) {
+        const int b = m->jnt_bodyid[j], a = m->jnt_qposadr[j];
+        const real *F = w->F + 3 * b, *T0 = w->Tq + 3 * b;
+        const real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
+        real d[3], t[3], tau[3];
+        for (int i = 0; i < 3; ++i) d[i] = anchor[i] - c[i];
+        cross3(d, F, t);
+        for (int i = 0; i < 3; ++i) tau[i] = T0[i] - t[i]; /* torque about the joint anchor */
+        switch (m->jnt_type[j]) {
+        case ORC_JNT_HINGE: grad[a] = dot3(axis, tau); break;
+        case ORC_JNT_SLIDE: grad[a] = dot3(axis, F); break;
+        case ORC_JNT_FREE:
+        case ORC_JNT_BALL: {
+            int qa = a;
+            real tl[3];
+            if (m->jnt_type[j] == ORC_JNT_FREE) {
+                for (int i = 0; i < 3; ++i) grad[a + i] = F[i];
+                qa = a + 3;
+                for (int i = 0; i < 3; ++i) tl[i] = tau[i];
+            } else {
+                /* torque expressed in the frame the ball rotation is applied in */
+                real qc[4] = {w->jprequat[4 * j], -w->jprequat[4 * j + 1], -w->jprequat[4 * j + 2], -w->jprequat[4 * j + 3]};
+                rotate(tau, qc, tl);
+            }
+            const real *qh = w->qf + qa; /* normalised quaternion (s, u) */
+            real uxt[3];
+            cross3(qh + 1, tl, uxt);
+            const real n = w->jnorm[j];
+            const real dn = n + (n == R(0) ? R(1e-6) : R(0));
+            grad[qa] = (R(-2) * dot3(tl, qh + 1)) / dn;
+            for (int i = 0; i < 3; ++i) grad[qa + 1 + i] = (R(2) * (qh[0] * tl[i] - uxt[i])) / dn;
+        } break;
+        default: break;
+        }
+    }
+    for (int i = 0; i < nq; ++i) grad[i] = qs_to_opt[i] ? grad[i] : R(0);
+    return loss;
+}
+
+static double q_loss_d(const orc_model *m, const float *q, const float *kp, const uint8_t *qs_to_opt,
+                       const uint8_t *kps_to_opt, const float *initial_q, float *grad);
+
+float orc_q_loss(const orc_model *m, const float *q, const float *kp, const uint8_t *qs_to_opt,
+                 const uint8_t *kps_to_opt, const float *initial_q, float *grad) {
+    return (float)q_loss_d(m, q, kp, qs_to_opt, kps_to_opt, initial_q, grad);
+}
+
+/* same, loss returned at the build's working precision (for finite-difference tests on the f64 twin) */
+double orc_q_loss_d(const orc_model *m, const float *q, const float *kp, const uint8_t *qs_to_opt,
+                    const uint8_t *kps_to_opt, const float *initial_q, float *grad) {
+    return q_loss_d(m, q, kp, qs_to_opt, kps_to_opt, initial_q, grad);
+}
+
+static double q_loss_d(const orc_model *m, const float *q, const float *kp, const uint8_t *qs_to_opt,
+                       const uint8_t *kps_to_opt, const float *initial_q, float *grad) {
+    ws_t *w = ws_new(m);
+    for (int i = 0; i < m->nq; ++i) { w->x[i] = R(q[i]); w->q0[i] = R(initial_q[i]); }
+    for (int i = 0; i < 3 * m->nsite; ++i) w->kp[i] = R(kp[i]);
+    real l = q_loss_ws(m, w, w->x, w->kp, qs_to_opt, kps_to_opt, w->q0, grad ? w->g : NULL);
+    if (grad) for (int i = 0; i < m->nq; ++i) grad[i] = (float)w->g[i];
+    ws_free(w);
+    return (double)l;
+}
+
+/* ---- jaxopt 0.8.5 ProjectedGradient.run ----------------------------------- */
+static inline real clipr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void q_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const uint8_t *qs_to_opt,
+                     const uint8_t *kps_to_opt, orc_pg_state *st) {
+    /* inputs in w->q0 (= init params AND initial_q, stac_core.py:83,90), w->kp, w->lb, w->ub;
+     * result in w->x. */
+    const int nq = m->nq;
+    const real eps = sizeof(real) == 4 ? R(1.1920929e-7) : R(2.220446049250313e-16);
+    real *x = w->x, *y = w->y, *g = w->g, *cand = w->cand, *gn = w->gn;
+    const real *lb = w->lb, *ub = w->ub;
+    for (int i = 0; i < nq; ++i) { x[i] = w->q0[i]; y[i] = w->q0[i]; }
+    real stepsize = R(1), t = R(1), error = (real)INFINITY;
+    int iter = 0, ls_evals = 0, grad_evals = 0;
+    if (p->maxiter > 0) {
+        do {
+            /* (f_y, g_y) = value_and_grad(fun)(y) */
+            const real fy = q_loss_ws(m, w, y, w->kp, qs_to_opt, kps_to_opt, w->q0, g);
+            ++grad_evals;
+            /* backtracking line search from the current stepsize */
+            real eta = stepsize;
+            for (int i = 0; i < nq; ++i) cand[i] = clipr(y[i] - eta * g[i], lb[i], ub[i]);
+            int n = 0;
+            for (;;) {
+                if (n >= p->maxls) break;
+                const real fc = q_loss_ws(m, w, cand, w->kp, qs_to_opt, kps_to_opt, w->q0, NULL);
+                ++ls_evals;
+                real sq = R(0), vd = R(0);
+                for (int i = 0; i < nq; ++i) {
+                    const real d = cand[i] - y[i];
+                    sq += d * d;
+                    vd += d * g[i];
+                }
+                const real lhs = eta * (fc - fy);
+                const real rhs = eta * vd + R(0.5) * sq + eps;
+                if (!(lhs > rhs)) break;
+                eta = eta * R(0.5);
+                for (int i = 0; i < nq; ++i) cand[i] = clipr(y[i] - eta * g[i], lb[i], ub[i]);
+                ++n;
+            }
+            const real next_step = (eta <= R(1e-6)) ? R(1) : eta / R(0.5);
+            const real tn = R(0.5) * (R(1) + rsqrt_(R(1) + R(4) * t * t));
+            const real beta = (t - R(1)) / tn;
+            for (int i = 0; i < nq; ++i) {
+                const real d = cand[i] - x[i];
+                y[i] = cand[i] + beta * d;
+                x[i] = cand[i];
+            }
+            /* error = || clip(x_next - grad(x_next)) - x_next ||_2 */
+            (void)q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, gn);
+            ++grad_evals;
+            real e2 = R(0);
+            for (int i = 0; i < nq; ++i) {
+                const real d = clipr(x[i] - gn[i], lb[i], ub[i]) - x[i];
+                e2 += d * d;
+            }
+            error = rsqrt_(e2);
+            stepsize = next_step;
+            t = tn;
+            ++iter;
+        } while (error > p->tol && iter < p->maxiter);
+    }
+    if (st) {
+        st->iter_num = iter;
+        st->stepsize = (float)stepsize;
+        st->error = (float)error;
+        st->t = (float)t;
+        st->ls_evals = ls_evals;
+        st->grad_evals = grad_evals;
+        st->loss = (float)q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, NULL);
+    }
+}
+
+static void ws_set_bounds(const orc_model *m, ws_t *w, const float *lb, const float *ub) {
+    for (int i = 0; i < m->nq; ++i) { w->lb[i] = R(lb[i]); w->ub[i] = R(ub[i]); }
+}
+
+void orc_q_opt(const orc_model *m, const orc_pg_params *p, const float *kp,
+               const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const float *q0,
+               const float *lb, const float *ub, float *params_out, orc_pg_state *state_out) {
+    ws_t *w = ws_new(m);
+    ws_set_bounds(m, w, lb, ub);
+    for (int i = 0; i < m->nq; ++i) w->q0[i] = R(q0[i]);
+    for (int i = 0; i < 3 * m->nsite; ++i) w->kp[i] = R(kp[i]);
+    q_opt_ws(m, w, p, qs_to_opt, kps_to_opt, state_out);
+    for (int i = 0; i < m->nq; ++i) params_out[i] = (float)w->x[i];
+    ws_free(w);
+}
+
+/* ---- offset phase (stac_core.py:102-172) -------------------------------------------------- */
+void orc_m_partial(const orc_model *m, const float *keypoints, const float *q, int32_t T,
+                   float *partial) {
+    const int K = m->nsite, nq = m->nq;
+    ws_t *w = ws_new(m);
+    real *s = (real *)calloc((size_t)3 * K + 2, sizeof(real));
+    real z2 = R(0);
+    for (int t = 0; t < T; ++t) {
+        for (int i = 0; i < nq; ++i) w->qf[i] = R(q[(size_t)t * nq + i]);
+        fk_ws(m, w, w->qf);
+        for (int k = 0; k < K; ++k) {
+            const int b = m->site_bodyid[k];
+            real mat[9], z[3];
+            quat_to_mat(w->xquat + 4 * b, mat);
+            for (int i = 0; i < 3; ++i) z[i] = R(keypoints[(size_t)t * 3 * K + 3 * k + i]) - w->xpos[3 * b + i];
+            /* s_k += R^T z */
+            for (int i = 0; i < 3; ++i) s[3 * k + i] += mat[0 + i] * z[0] + mat[3 + i] * z[1] + mat[6 + i] * z[2];
+            z2 += z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
+        }
+    }
+    for (int i = 0; i < 3 * K; ++i) partial[i] = (float)s[i];
+    partial[3 * K] = (float)z2;
+    partial[3 * K + 1] = (float)T;
+    free(s);
+    ws_free(w);
+}
+
+void orc_m_finish(int32_t K, const float *partial, const float *initial_offsets,
+                  const float *is_regularized, float reg_coef, float *params_out,
+                  float *error_out) {
+    const real T = R(partial[3 * K + 1]), z2 = R(partial[3 * K]), lam = R(reg_coef);
+    real ms = R(0), mm = R(0), reg = R(0);
+    for (int i = 0; i < 3 * K; ++i) {
+        const real d = R(is_regularized[i]), s = R(partial[i]), m0 = R(initial_offsets[i]);
+        const real denom = T + lam * d;
+        const real numer = s + lam * d * m0;
+        const real ms_i = numer / denom;
+        params_out[i] = (float)ms_i;
+        ms += ms_i * s;
+        mm += ms_i * ms_i;
+        const real dr = d * (ms_i - m0);
+        reg += dr * dr;
+    }
+    if (error_out) *error_out = (float)((z2 - R(2) * ms + T * mm) + lam * reg);
+}
+
+void orc_m_opt(const orc_model *m, const float *keypoints, const float *q, int32_t T,
+               const float *initial_offsets, const float *is_regularized, float reg_coef,
+               float *params_out, float *error_out) {
+    float *partial = (float *)calloc((size_t)3 * m->nsite + 2, sizeof(float));
+    orc_m_partial(m, keypoints, q, T, partial);
+    orc_m_finish(m->nsite, partial, initial_offsets, is_regularized, reg_coef, params_out, error_out);
+    free(partial);
+}
+
+/* ---- phase drivers (compute_stac.py) -------------------------------------------------------- */
+/* utils.replace_qs: qpos <- make_qs(q0, mask, params); kinematics (normalises quaternions). */
+static void replace_qs_ws(const orc_model *m, ws_t *w, const uint8_t *mask, real *qpos) {
+    for (int i = 0; i < m->nq; ++i) {
+        const real mi = mask ? (mask[i] ? R(1) : R(0)) : R(1);
+        qpos[i] = mask ? (R(1) - mi) * w->q0[i] + mi * w->x[i] : w->x[i];
+    }
+    fk_ws(m, w, qpos);
+}
+
+static void root_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const float *kp_clip,
+                        int frame, int root_kp_idx, int root_dims, const uint8_t *trunk_kps,
+                        real *qpos, orc_pg_state *st) {
+    const int nq = m->nq, K = m->nsite;
+    uint8_t *qs = (uint8_t *)calloc(nq, 1), *kps = (uint8_t *)calloc(3 * K, 1);
+    for (int i = 0; i < root_dims && i < nq; ++i) qs[i] = 1;
+    for (int k = 0; k < K; ++k) kps[3 * k] = kps[3 * k + 1] = kps[3 * k + 2] = trunk_kps[k];
+    const float *kpf = kp_clip + (size_t)frame * 3 * K;
+    for (int i = 0; i < 3 * K; ++i) w->kp[i] = R(kpf[i]);
+    for (int pass = 0; pass < 2; ++pass) { /* compute_stac.py:57-98: two identical solves */
+        for (int i = 0; i < nq; ++i) w->q0[i] = qpos[i];
+        for (int i = 0; i < 3; ++i) w->q0[i] = R(kpf[3 * root_kp_idx + i]);
+        q_opt_ws(m, w, p, qs, kps, st);
+        replace_qs_ws(m, w, qs, qpos);
+    }
+    free(qs); free(kps);
+}
+
+void orc_root_optimization(const orc_model *m, const orc_pg_params *p, const float *kp_clip,
+                           int32_t frame, int32_t root_kp_idx, int32_t root_dims, const float *lb,
+                           const float *ub, const uint8_t *trunk_kps, float *qpos,
+                           orc_pg_state *last_state) {
+    ws_t *w = ws_new(m);
+    ws_set_bounds(m, w, lb, ub);
+    real *qp = (real *)malloc(sizeof(real) * m->nq);
+    for (int i = 0; i < m->nq; ++i) qp[i] = R(qpos[i]);
+    root_opt_ws(m, w, p, kp_clip, frame, root_kp_idx, root_dims, trunk_kps, qp, last_state);
+    for (int i = 0; i < m->nq; ++i) qpos[i] = (float)qp[i];
+    free(qp);
+    ws_free(w);
+}
+
+static void pose_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const float *kp_clip,
+                        int F, const uint8_t *part_masks, int P, real *qpos, float *qposes,
+                        float *xposes, float *xquats, float *markers, float *frame_error,
+                        uint32_t *counters) {
+    const int nq = m->nq, K = m->nsite, nb = m->nbody;
+    uint8_t *all_q = (uint8_t *)malloc(nq), *all_k = (uint8_t *)malloc(3 * K);
+    memset(all_q, 1, nq);
+    memset(all_k, 1, 3 * K);
+    for (int f = 0; f < F; ++f) {
+        orc_pg_state st;
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        const float *kpf = kp_clip + (size_t)f * 3 * K;
+        for (int i = 0; i < 3 * K; ++i) w->kp[i] = R(kpf[i]);
+        /* full-body solve (compute_stac.py:217-231) */
+        for (int i = 0; i < nq; ++i) w->q0[i] = qpos[i];
+        q_opt_ws(m, w, p, all_q, all_k, &st);
+        cnt[0] += st.iter_num; cnt[1] += st.ls_evals; cnt[2] += st.grad_evals; cnt[3] += 1;
+        replace_qs_ws(m, w, NULL, qpos);
+        /* individual part solves (compute_stac.py:233-250) */
+        for (int pi = 0; pi < P; ++pi) {
+            const uint8_t *mask = part_masks + (size_t)pi * nq;
+            for (int i = 0; i < nq; ++i) w->q0[i] = qpos[i];
+            q_opt_ws(m, w, p, mask, all_k, &st);
+            cnt[0] += st.iter_num; cnt[1] += st.ls_evals; cnt[2] += st.grad_evals; cnt[3] += 1;
+            replace_qs_ws(m, w, mask, qpos);
+        }
+        if (qposes) for (int i = 0; i < nq; ++i) qposes[(size_t)f * nq + i] = (float)qpos[i];
+        if (xposes) for (int i = 0; i < nb * 3; ++i) xposes[(size_t)f * nb * 3 + i] = (float)w->xpos[i];
+        if (xquats) for (int i = 0; i < nb * 4; ++i) xquats[(size_t)f * nb * 4 + i] = (float)w->xquat[i];
+        if (markers) for (int i = 0; i < K * 3; ++i) markers[(size_t)f * K * 3 + i] = (float)w->sx[i];
+        if (frame_error) frame_error[f] = st.error; /* PG residual of the LAST solve (compute_stac.py:252) */
+        if (counters) for (int i = 0; i < 4; ++i) counters[(size_t)f * 4 + i] = cnt[i];
+    }
+    free(all_q); free(all_k);
+}
+
+void orc_pose_optimization(const orc_model *m, const orc_pg_params *p, const float *kp_clip,
+                           int32_t F, const float *lb, const float *ub,
+                           const uint8_t *part_masks, int32_t P, float *qpos, float *qposes,
+                           float *xposes, float *xquats, float *markers, float *frame_error,
+                           uint32_t *counters) {
+    ws_t *w = ws_new(m);
+    ws_set_bounds(m, w, lb, ub);
+    real *qp = (real *)malloc(sizeof(real) * m->nq);
+    for (int i = 0; i < m->nq; ++i) qp[i] = R(qpos[i]);
+    pose_opt_ws(m, w, p, kp_clip, F, part_masks, P, qp, qposes, xposes, xquats, markers, frame_error, counters);
+    for (int i = 0; i < m->nq; ++i) qpos[i] = (float)qp[i];
+    free(qp);
+    ws_free(w);
+}
+
+int32_t orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_ik_clips(const orc_model *m, const orc_pg_params *p, const float *kp, int32_t C,
+                  int32_t F, const float *lb, const float *ub, const uint8_t *part_masks,
+                  int32_t P, const uint8_t *trunk_kps, int32_t root_kp_idx, int32_t root_dims,
+                  int32_t do_root_opt, const float *q_init, float *qposes, float *xposes,
+                  float *xquats, float *markers, float *frame_error, uint32_t *counters,
+                  int32_t nthreads) {
+    const int nq = m->nq, K = m->nsite, nb = m->nbody;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+#endif
+    for (int c = 0; c < C; ++c) {
+        ws_t *w = ws_new(m);
+        ws_set_bounds(m, w, lb, ub);
+        real *qp = (real *)malloc(sizeof(real) * nq);
+        for (int i = 0; i < nq; ++i) qp[i] = q_init ? R(q_init[(size_t)c * nq + i]) : w->qpos0[i];
+        const float *kpc = kp + (size_t)c * F * 3 * K;
+        if (do_root_opt) root_opt_ws(m, w, p, kpc, 0, root_kp_idx, root_dims, trunk_kps, qp, NULL);
+        pose_opt_ws(m, w, p, kpc, F, part_masks, P, qp,
+                    qposes ? qposes + (size_t)c * F * nq : NULL,
+                    xposes ? xposes + (size_t)c * F * nb * 3 : NULL,
+                    xquats ? xquats + (size_t)c * F * nb * 4 : NULL,
+                    markers ? markers + (size_t)c * F * K * 3 : NULL,
+                    frame_error ? frame_error + (size_t)c * F : NULL,
+                    counters ? counters + (size_t)c * F * 4 : NULL);
+        free(qp);
+        ws_free(w);
+    }
+    (void)nthreads;
+}

@@ -1,0 +1,171 @@
+"""Data loading / saving with the reference's conventions.
+
+Mirrors ``stac_mjx/io.py``: ``StacData`` (:17-36), ``load_data`` (:39-98, keypoints re-ordered to
+``KEYPOINT_MODEL_PAIRS`` key order, scaled by ``MOCAP_SCALE_FACTOR``, flattened to
+``[frames, 3K]`` as ``[kp0.x, kp0.y, kp0.z, kp1.x, ...]``), ``save_data_to_h5`` (:194-237) and
+``load_stac_data`` (:240-278).
+
+``.mat`` needs only scipy.  ``.h5``/``.nwb`` inputs and ``.h5`` outputs need h5py, which is
+optional in this image: without it results are written as ``.npz`` holding the same dataset
+names (the output path keeps its stem, the suffix becomes ``.npz``).
+"""
+
+from __future__ import annotations
+
+from dataclasses import asdict, dataclass, field
+from pathlib import Path
+
+import numpy as np
+import yaml
+
+from .config import ConfigNode, validate_config
+
+try:  # optional
+    import h5py  # type: ignore
+except Exception:  # pragma: no cover - depends on the image
+    h5py = None
+
+
+@dataclass
+class StacData:
+    """Output record (same fields as ``stac_mjx.io.StacData``)."""
+
+    qpos: np.ndarray
+    xpos: np.ndarray
+    xquat: np.ndarray
+    marker_sites: np.ndarray
+    offsets: np.ndarray
+    kp_data: np.ndarray
+    names_qpos: list
+    names_xpos: list
+    kp_names: list
+    qvel: np.ndarray = field(default_factory=lambda: np.array([]))
+
+    def as_dict(self) -> dict:
+        return asdict(self)
+
+
+def load_dannce(filename, names_filename=None):
+    """``.mat`` loader (io.py:101-124): returns ``pred`` as stored, i.e. [frames, xyz, keypoints]."""
+    import scipy.io as spio
+
+    node_names = None
+    if names_filename is not None:
+        mat = spio.loadmat(names_filename)
+        node_names = [item[0] for sublist in mat["joint_names"] for item in sublist]
+    data = spio.loadmat(filename, struct_as_record=False, squeeze_me=True)["pred"]
+    return np.asarray(data), node_names
+
+
+def load_h5(filename):
+    """``.h5`` loader (io.py:150-170): dataset ``tracks`` [frames, 1, keypoints, xyz] -> [frames, xyz, keypoints]."""
+    if h5py is None:
+        raise ImportError("h5py is required to read .h5 mocap files")
+    with h5py.File(filename, "r") as f:
+        data = np.array(f["tracks"][()])
+    data = np.squeeze(data, axis=1)
+    return np.transpose(data, (0, 2, 1)), None
+
+
+def load_nwb(filename):
+    """``.nwb`` loader (io.py:127-147) read through plain h5py (pynwb/ndx_pose are not needed for the
+    PoseEstimationSeries layout): returns [frames, xyz, keypoints] and the node names."""
+    if h5py is None:
+        raise ImportError("h5py is required to read .nwb mocap files")
+    with h5py.File(filename, "r") as f:
+        pe = f["processing/behavior/PoseEstimation"]
+        if "nodes" in pe:
+            node_names = [n.decode() if isinstance(n, bytes) else str(n) for n in pe["nodes"][()]]
+        else:
+            node_names = [k for k in pe.keys() if isinstance(pe[k], h5py.Group) and "data" in pe[k]]
+        data = np.stack([pe[n]["data"][()] for n in node_names], axis=-1)
+    return data, node_names
+
+
+def load_data(cfg, base_path: Path | None = None):
+    """Load, re-order, scale and flatten mocap data (io.py:39-98).
+
+    Returns ``(kp_data [frames, 3K] float32, sorted_kp_names)``.
+    """
+    base_path = Path.cwd() if base_path is None else Path(base_path)
+    file_path = base_path / cfg.stac.data_path
+    if file_path.suffix == ".mat":
+        label3d_path = cfg.model.get("KP_NAMES_LABEL3D_PATH", None)
+        data, kp_names = load_dannce(str(file_path), names_filename=label3d_path)
+    elif file_path.suffix == ".nwb":
+        data, kp_names = load_nwb(file_path)
+    elif file_path.suffix == ".h5":
+        data, kp_names = load_h5(file_path)
+    else:
+        raise ValueError("Unsupported file extension. Please provide a .mat, .nwb, or .h5 file.")
+
+    kp_names = kp_names or cfg.model.get("KP_NAMES", None)
+    if kp_names is None:
+        raise ValueError(
+            "Keypoint names not provided. Please provide an ordered list of keypoint names "
+            "corresponding to the keypoint data order."
+        )
+    kp_names = list(kp_names)
+    if len(kp_names) != data.shape[2]:
+        raise ValueError(
+            f"Number of keypoint names ({len(kp_names)}) is not the same as the number of keypoints in data ({data.shape[2]})"
+        )
+    model_inds = [kp_names.index(src) for src in cfg.model.KEYPOINT_MODEL_PAIRS.keys()]
+    sorted_kp_names = [kp_names[i] for i in model_inds]
+    data = np.asarray(data, dtype=np.float64) * cfg.model.MOCAP_SCALE_FACTOR  # float64, then cast (io.py:93-94)
+    data = data[:, :, model_inds].astype(np.float32)
+    data = np.transpose(data, (0, 2, 1)).reshape(data.shape[0], -1)
+    return np.ascontiguousarray(data), sorted_kp_names
+
+
+_DATASETS = ("kp_data", "marker_sites", "offsets", "qpos", "qvel", "xpos", "xquat")
+
+
+def save_data_to_h5(config, kp_names, names_qpos, names_xpos, kp_data, marker_sites, offsets, qpos,
+                    xpos, xquat, qvel, file_path) -> Path:  # fmt: skip
+    """Write the reference's output contract (io.py:194-237).  Returns the path actually written."""
+    file_path = Path(file_path)
+    cfg_yaml = config.to_yaml() if isinstance(config, ConfigNode) else yaml.safe_dump(config, sort_keys=False)
+    arrays = dict(kp_data=kp_data, marker_sites=marker_sites, offsets=offsets, qpos=qpos,
+                  qvel=np.asarray(qvel), xpos=xpos, xquat=xquat)  # fmt: skip
+    if h5py is not None and file_path.suffix in (".h5", ".hdf5"):
+        with h5py.File(file_path, "w") as f:
+            f.create_dataset("config", data=np.bytes_(cfg_yaml))
+            f.create_dataset("kp_names", data=np.array(kp_names, dtype="S"))
+            f.create_dataset("names_qpos", data=np.array(names_qpos, dtype="S"))
+            f.create_dataset("names_xpos", data=np.array(names_xpos, dtype="S"))
+            for k, v in arrays.items():
+                f.create_dataset(k, data=np.asarray(v), compression="gzip" if np.asarray(v).ndim else None)
+        return file_path
+    out = file_path.with_suffix(".npz")
+    np.savez_compressed(
+        out, config=np.bytes_(cfg_yaml), kp_names=np.array(kp_names, dtype="S"),
+        names_qpos=np.array(names_qpos, dtype="S"), names_xpos=np.array(names_xpos, dtype="S"),
+        **{k: np.asarray(v) for k, v in arrays.items()})  # fmt: skip
+    return out
+
+
+def load_stac_data(file_path):
+    """Read back a result file (io.py:240-278).  Accepts the ``.h5`` path or its ``.npz`` stand-in."""
+    file_path = Path(file_path)
+    if not file_path.exists() and file_path.with_suffix(".npz").exists():
+        file_path = file_path.with_suffix(".npz")
+    if file_path.suffix == ".npz":
+        with np.load(file_path, allow_pickle=False) as f:
+            d = {k: f[k] for k in f.files}
+        cfg_yaml = bytes(d["config"]).decode("utf-8")
+    else:
+        if h5py is None:
+            raise ImportError("h5py is required to read .h5 result files")
+        with h5py.File(file_path, "r") as f:
+            d = {k: f[k][()] for k in f.keys()}
+        cfg_yaml = d["config"].decode("utf-8")
+    config = validate_config(yaml.safe_load(cfg_yaml))
+
+    def names(a):
+        return [n.decode("utf-8") if isinstance(n, bytes) else str(n) for n in np.asarray(a).tolist()]
+
+    return config, StacData(
+        kp_names=names(d["kp_names"]), names_qpos=names(d["names_qpos"]), names_xpos=names(d["names_xpos"]),
+        kp_data=d["kp_data"], marker_sites=d["marker_sites"], offsets=d["offsets"], qpos=d["qpos"],
+        qvel=d["qvel"], xpos=d["xpos"], xquat=d["xquat"])  # fmt: skip

@@ -1,0 +1,103 @@
+"""Test configuration: registers the `gpu` marker and shared fixtures.
+
+`-m "not gpu"` tests run on CPU (oracle vs golden vectors, host logic, C-ABI symbol check,
+world_size-2 gloo tests); `-m gpu` tests are the HIP-vs-oracle parity tests proper.
+"""
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+REFERENCE = Path("/root/reference")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def rodent_cfg():
+    with open(GOLDEN / "rodent_model_cfg.json") as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def rodent_setup(rodent_cfg):
+    from stac_mjx_amd.fit_model import finish_fit_setup
+    from stac_mjx_amd.mjcf import ModelTables
+
+    tables = ModelTables.load(GOLDEN / "rodent_tables.npz")
+    return finish_fit_setup(tables, rodent_cfg, list(rodent_cfg["KEYPOINT_MODEL_PAIRS"].keys()))
+
+
+@pytest.fixture(scope="session")
+def rodent_setup_legacy(rodent_cfg):
+    from stac_mjx_amd.fit_model import finish_fit_setup
+    from stac_mjx_amd.mjcf import ModelTables
+
+    tables = ModelTables.load(GOLDEN / "rodent_tables_legacy.npz")
+    return finish_fit_setup(tables, rodent_cfg, list(rodent_cfg["KEYPOINT_MODEL_PAIRS"].keys()))
+
+
+@pytest.fixture(scope="session")
+def fly_setup():
+    from stac_mjx_amd.fit_model import finish_fit_setup
+    from stac_mjx_amd.mjcf import ModelTables
+
+    with open(GOLDEN / "fly_model_cfg.json") as fh:
+        cfg = json.load(fh)
+    tables = ModelTables.load(GOLDEN / "fly_tables.npz")
+    return finish_fit_setup(tables, cfg, list(cfg["KEYPOINT_MODEL_PAIRS"].keys()))
+
+
+@pytest.fixture(scope="session")
+def demo_viz():
+    with np.load(GOLDEN / "demo_viz_golden.npz") as d:
+        return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
+def rodent_mocap():
+    return np.load(GOLDEN / "rodent_mocap_1000.npy")
+
+
+# Toy model of the reference's m_opt known-answer tests (tests/unit/test_m_opt.py:17-37):
+# three bodies in a chain, hinges about z, x, y, one marker site per body.
+MINIMAL_XML = """
+<mujoco>
+  <worldbody>
+    <body name="b1" pos="1 0 0">
+      <joint name="j1" type="hinge" axis="0 0 1"/>
+      <site name="s1" pos="0.1 0.2 0.3"/>
+      <body name="b2" pos="0 1 0">
+        <joint name="j2" type="hinge" axis="1 0 0"/>
+        <site name="s2" pos="0.4 0.5 0.6"/>
+        <body name="b3" pos="0 0 1">
+          <joint name="j3" type="hinge" axis="0 1 0"/>
+          <site name="s3" pos="0.15 0.25 0.35"/>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+@pytest.fixture(scope="session")
+def toy_tables():
+    from stac_mjx_amd.mjcf import compile_mjcf
+
+    return compile_mjcf(MINIMAL_XML, from_string=True)
