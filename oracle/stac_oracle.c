@@ -99,6 +99,7 @@ typedef struct {
     real *body_pos, *body_quat, *jnt_pos, *jnt_axis, *qpos0, *site_pos;
     real *qf, *xpos, *xquat, *xanchor, *xaxis, *jprequat, *jnorm, *sx, *F, *Tq;
     real *x, *y, *g, *cand, *xn, *gn, *tmp, *kp, *q0, *lb, *ub;
+    int ref_body; /* moments of the gradient wrenches are taken about xpos[ref_body] */
 } ws_t;
 
 static ws_t *ws_new(const orc_model *m) {
@@ -135,6 +136,20 @@ static ws_t *ws_new(const orc_model *m) {
     w->xn = p; p += nq; w->gn = p; p += nq; w->tmp = p; p += nq; w->q0 = p; p += nq;
     w->lb = p; p += nq; w->ub = p; p += nq;
     w->kp = p; p += K * 3;
+    /* ref_body = first body, ordered by (depth, id), that is an ancestor-or-self of a fit site
+     * (the root body for every model of the reference). */
+    {
+        int *depth = (int *)calloc(nb, sizeof(int));
+        unsigned char *act = (unsigned char *)calloc(nb, 1);
+        for (int b = 1; b < nb; ++b) depth[b] = depth[m->body_parentid[b]] + 1;
+        for (int k = 0; k < K; ++k)
+            for (int b = m->site_bodyid[k]; b > 0 && !act[b]; b = m->body_parentid[b]) act[b] = 1;
+        w->ref_body = nb > 1 ? 1 : 0;
+        int best = 1 << 30;
+        for (int b = 1; b < nb; ++b)
+            if (act[b] && depth[b] < best) { best = depth[b]; w->ref_body = b; }
+        free(depth); free(act);
+    }
     return w;
 }
 static void ws_free(ws_t *w) {
@@ -249,8 +264,8 @@ static real q_loss_ws(const orc_model *m, ws_t *w, const real *q, const real *kp
     }
     if (!grad) return loss;
 
-    /* dL/dx_k = -2 w (kp - x_k).  Subtree wrench sums about c = xpos[1] (root body). */
-    const real *c = w->xpos + 3;
+    /* dL/dx_k = -2 w (kp - x_k).  Subtree wrench sums about c = xpos[ref_body] (root body). */
+    const real *c = w->xpos + 3 * w->ref_body;
     memset(w->F, 0, sizeof(real) * nb * 3);
     memset(w->Tq, 0, sizeof(real) * nb * 3);
     for (int k = 0; k < K; ++k) {
@@ -429,9 +444,12 @@ void orc_m_partial(const orc_model *m, const float *keypoints, const float *q, i
     ws_t *w = ws_new(m);
     real *s = (real *)calloc((size_t)3 * K + 2, sizeof(real));
     real z2 = R(0);
+    /* Summation order (XLA's is unspecified): per frame the K-site subtotal of |z|^2, then frames
+     * accumulated in index order per component -- the order the HIP kernels reproduce exactly. */
     for (int t = 0; t < T; ++t) {
         for (int i = 0; i < nq; ++i) w->qf[i] = R(q[(size_t)t * nq + i]);
         fk_ws(m, w, w->qf);
+        real z2t = R(0);
         for (int k = 0; k < K; ++k) {
             const int b = m->site_bodyid[k];
             real mat[9], z[3];
@@ -439,8 +457,9 @@ void orc_m_partial(const orc_model *m, const float *keypoints, const float *q, i
             for (int i = 0; i < 3; ++i) z[i] = R(keypoints[(size_t)t * 3 * K + 3 * k + i]) - w->xpos[3 * b + i];
             /* s_k += R^T z */
             for (int i = 0; i < 3; ++i) s[3 * k + i] += mat[0 + i] * z[0] + mat[3 + i] * z[1] + mat[6 + i] * z[2];
-            z2 += z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
+            z2t += z[0] * z[0] + z[1] * z[1] + z[2] * z[2];
         }
+        z2 += z2t;
     }
     for (int i = 0; i < 3 * K; ++i) partial[i] = (float)s[i];
     partial[3 * K] = (float)z2;

@@ -1,0 +1,48 @@
+"""Builds the HIP extension in-tree: ``stac_mjx_amd/csrc/libstac_hip.so`` (gfx950 only).
+
+``hipcc`` cross-compiles without a GPU.  ``-ffp-contract=off -fno-fast-math`` is part of the
+arithmetic contract of the kernels (bit-identical to the CPU oracle), not a tuning choice.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libstac_hip.so"
+SOURCES = [CSRC / "stac_kernels.hip", CSRC / "stac_abi.hip"]
+HEADERS = [CSRC / "stac_plan.hpp", CSRC.parents[1] / "include" / "stac_hip.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libstac_hip.so)")
+
+
+def is_stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), *FLAGS, *map(str, SOURCES), "-o", str(LIB)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    if verbose:
+        print(res.stdout + res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_extension(force=True, verbose=True))

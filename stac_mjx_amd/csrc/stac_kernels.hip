@@ -1,0 +1,708 @@
+// stac_kernels.hip -- gfx950 (CDNA4) kernels of the STAC pose-fitting hot path.
+//
+// What runs here (reference = talmolab/stac-mjx):
+//   q_phase_kernel   per-frame q_phase: q_loss (stac_mjx/stac_core.py:27-63) = MJX forward kinematics
+//                    down the body tree -> marker site_xpos -> masked keypoint residual, its analytic
+//                    gradient (replaces jax.grad), and the jaxopt ProjectedGradient iteration around it
+//                    (stac_core.py:66-99,182-191), sequenced like compute_stac.root_optimization /
+//                    pose_optimization (stac_mjx/compute_stac.py:17-104,170-278): one warm-started
+//                    chain per clip, persistent over the clip's frames.
+//   fk_kernel        utils.kinematics on N poses (stac_mjx/utils.py:49-60) for the xpos/xquat/marker
+//                    outputs of pose_optimization (compute_stac.py:261-264).
+//   m_* kernels      the cross-frame sums and closed form of _m_opt (stac_core.py:102-172).
+//
+// Execution model: a workgroup is ONE 64-lane wavefront.  A wavefront is split into 64/G groups of
+// G lanes; each group owns one chain (clip) and cooperates on it: lanes of a group take the bodies
+// of one tree level, the marker sites, the joints, and 1/G of every nq-vector (held in registers).
+// The model "plan" (active subtree tables) and the per-chain transforms live in LDS.  Every group
+// runs its own solver state machine, so chains of one wavefront may be in different solves, line
+// searches or frames: each trip round the main loop is one q_loss evaluation for every group.
+//
+// Arithmetic contract: every float operation sequence here is the one of oracle/stac_oracle.c
+// (same expression trees, same summation orders, no FMA contraction: build with
+// -ffp-contract=off), so results are bit-identical to the CPU oracle; tests/test_gpu_parity.py
+// checks exactly that.  There is no dense contraction on this path, hence no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "stac_plan.hpp"
+
+namespace stac {
+
+// ------------------------------------------------------------------------------------------------
+// math (mirrors oracle/stac_oracle.c: dot3, cross3, rotate, qmul, normalize4, sincos_, quat_to_mat)
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 add3(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+// rotate(vec, quat): r = 2(u.v)u + (s^2 - u.u)v + 2 s (u x v)
+__device__ __forceinline__ V3 rotate(V3 v, Q4 q) {
+    const float s = q.w;
+    const V3 u = {q.x, q.y, q.z};
+    const float uv = dot3(u, v), uu = dot3(u, u);
+    const V3 c = cross3(u, v);
+    const float k = s * s - uu, s2 = 2.0f * s;
+    V3 r;
+    r.x = (2.0f * (uv * u.x) + k * v.x) + s2 * c.x;
+    r.y = (2.0f * (uv * u.y) + k * v.y) + s2 * c.y;
+    r.z = (2.0f * (uv * u.z) + k * v.z) + s2 * c.z;
+    return r;
+}
+__device__ __forceinline__ Q4 qmul(Q4 u, Q4 v) {
+    Q4 r;
+    r.w = u.w * v.w - u.x * v.x - u.y * v.y - u.z * v.z;
+    r.x = u.w * v.x + u.x * v.w + u.y * v.z - u.z * v.y;
+    r.y = u.w * v.y - u.x * v.z + u.y * v.w + u.z * v.x;
+    r.z = u.w * v.z + u.x * v.y - u.y * v.x + u.z * v.w;
+    return r;
+}
+// normalize(x) = x / (|x| + 1e-6 [|x| == 0]); returns |x| through *n
+__device__ __forceinline__ Q4 normalize4(Q4 q, float *n_out) {
+    const float n = __builtin_sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const float d = n + (n == 0.0f ? 1e-6f : 0.0f);
+    *n_out = n;
+    return {q.w / d, q.x / d, q.y / d, q.z / d};
+}
+// Cody-Waite + cephes minimax sin/cos, plain mul/add: the oracle's sincos_ operation for operation.
+__device__ __forceinline__ void sincos_(float x, float *sn, float *cs) {
+    const float k = __builtin_rintf(x * 0.636619772367581343f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    const float s0 = r + r * z * ps;
+    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float c0 = (1.0f - 0.5f * z) + z * z * pc;
+    const int q = ((int)k) & 3;
+    const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ Q4 ld4(const float *p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ void st4(float *p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+
+enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3 };
+enum : int { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
+
+// One wavefront per workgroup: a barrier only has to order this wave's LDS traffic.
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+// ------------------------------------------------------------------------------------------------
+// q_phase kernel
+// ------------------------------------------------------------------------------------------------
+template <int G, int NQR>
+__global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
+    extern __shared__ float lds[];
+    constexpr int CPW = 64 / G;
+    const PlanHeader &H = a.h;
+    const int lane = threadIdx.x;
+    const int grp = lane / G, lg = lane % G;
+    const int nq = H.nq, K = H.K, nqpad = H.nqpad;
+
+    // ---- stage the plan into LDS -------------------------------------------------------------
+    float *P = lds;
+    const int *PI = reinterpret_cast<const int *>(lds);
+    for (int i = lane; i < H.total_words; i += 64) P[i] = a.plan[i];
+    const int plan_words = (H.total_words + 3) & ~3;
+    // per-kind qs_to_opt bit masks, one 32-bit word per (kind, lane-in-group): bit r <-> element r*G+lg
+    uint32_t *MB = reinterpret_cast<uint32_t *>(lds + plan_words);
+    const int nkinds = a.single ? 1 : a.P + 3;
+    for (int i = lane; i < nkinds * G; i += 64) {
+        const int kind = i / G, l = i % G;
+        uint32_t bits = 0;
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + l;
+            if (e < nq && a.masks[kind * nqpad + e]) bits |= (1u << r);
+        }
+        MB[i] = bits;
+    }
+    float *CB = lds + plan_words + a.mb_words + grp * H.chain_stride;  // this chain's region
+    float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jq = CB + H.c_jq, *jn = CB + H.c_jn;
+    float *sw = CB + H.c_sw, *gg = CB + H.c_sw, *bw = CB + H.c_bw, *r2 = CB + H.c_bw, *red = CB + H.c_bw;
+    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
+    wave_sync();
+
+    const int *lev_adr = PI + H.off_lev_adr, *ab_parent = PI + H.off_ab_parent;
+    const int *ab_jadr = PI + H.off_ab_jadr, *ab_jnum = PI + H.off_ab_jnum;
+    const int *ab_sadr = PI + H.off_ab_sadr, *ab_snum = PI + H.off_ab_snum;
+    const int *ab_cadr = PI + H.off_ab_cadr, *ab_cnum = PI + H.off_ab_cnum;
+    const int *site_list = PI + H.off_site_list, *child_list = PI + H.off_child_list;
+    const float *ab_pos = P + H.off_ab_pos, *ab_quat = P + H.off_ab_quat;
+    const int *aj_type = PI + H.off_aj_type, *aj_qadr = PI + H.off_aj_qadr, *aj_slot = PI + H.off_aj_slot;
+    const float *aj_pos = P + H.off_aj_pos, *aj_axis = P + H.off_aj_axis, *aj_q0 = P + H.off_aj_q0;
+    const int *site_slot = PI + H.off_site_slot;
+    const float *site_pos = P + H.off_site_pos;
+    const float *lbv = P + H.off_lb, *ubv = P + H.off_ub, *qpos0 = P + H.off_qpos0;
+    const int *quat_adr = PI + H.off_quat_adr;
+
+    // ---- per-chain solver state (uniform inside a group) ------------------------------------------
+    const int chain = blockIdx.x * CPW + grp;
+    int st = chain < a.C ? ST_VG_Y : ST_DONE;
+    int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
+    int frame = 0, iter = 0, nls = 0;
+    float stepsize = 1.0f, t = 1.0f, tn = 1.0f, next_step = 1.0f, eta = 1.0f, fy = 0.0f, fx = 0.0f;
+    float error = __builtin_inff();
+    uint32_t c_iter = 0, c_ls = 0, c_grad = 0, c_solves = 0;
+    uint32_t s_ls = 0, s_grad = 0;  // per-solve counters (single mode)
+
+    float x[NQR], y[NQR], g[NQR], cand[NQR], q0[NQR];
+    const float eps = 1.1920929e-7f;
+
+    // bx[0] = world
+    if (lg == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 0.f; bx[3] = 1.f; bx[4] = 0.f; bx[5] = 0.f; bx[6] = 0.f; }
+
+    // initial qpos, keypoints of frame 0, first solve
+    const size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
+#pragma unroll
+    for (int r = 0; r < NQR; ++r) {
+        const int e = r * G + lg;
+        float v = 0.f;
+        if (e < nq && st != ST_DONE) v = a.q_init ? a.q_init[(size_t)chain * nq + e] : qpos0[e];
+        q0[r] = v;
+    }
+    if (st != ST_DONE) {
+        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + i];
+        if (!a.single && kind < 2) {  // root pass: q0[:3] = keypoint of the root marker (compute_stac.py:57-59)
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                if (e < 3) q0[r] = a.kp[kp_chain + 3 * a.root_kp_idx + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; cand[r] = q0[r]; }
+    wave_sync();
+
+    // ================================= main loop: one q_loss evaluation per trip ==================
+    while (__any(st != ST_DONE)) {
+        const int st_in = st;
+        const uint32_t mbits = MB[kind * G + lg];
+        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X);
+        const bool any_grad = __any(want_grad);
+
+        // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            if (e < nq) {
+                const float pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cand[r] : x[r]);
+                const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
+                qe[e] = (1.0f - mi) * q0[r] + mi * pt;
+            }
+        }
+        wave_sync();
+
+        // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
+        for (int lev = 0; lev < H.nlev; ++lev) {
+            const int s_end = lev_adr[lev + 1];
+            for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
+                const float *pp = bx + ab_parent[s] * 7;
+                const V3 ppos = ld3(pp);
+                const Q4 pquat = ld4(pp + 3);
+                V3 pos = add3(ppos, rotate(ld3(ab_pos + 3 * s), pquat));
+                Q4 quat = qmul(pquat, ld4(ab_quat + 4 * s));
+                const int j0 = ab_jadr[s], j1 = j0 + ab_jnum[s];
+                for (int j = j0; j < j1; ++j) {
+                    const int ty = aj_type[j], ad = aj_qadr[j];
+                    const V3 jp = ld3(aj_pos + 3 * j), jax = ld3(aj_axis + 3 * j);
+                    V3 anchor, axis;
+                    if (ty == JFREE) {
+                        anchor = ld3(qe + ad);
+                        pos = anchor;
+                        axis = {0.f, 0.f, 1.f};
+                        float n;
+                        quat = normalize4(ld4(qe + ad + 3), &n);
+                        st4(qe + ad + 3, quat);  // written back, like MJX
+                        jn[j] = n;
+                    } else if (ty == JHINGE) {
+                        anchor = add3(rotate(jp, quat), pos);
+                        axis = rotate(jax, quat);
+                        const float angle = qe[ad] - aj_q0[j];
+                        float sn, cs;
+                        sincos_(angle * 0.5f, &sn, &cs);
+                        const Q4 qloc = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
+                        quat = qmul(quat, qloc);
+                        pos = sub3(anchor, rotate(jp, quat));
+                    } else if (ty == JSLIDE) {
+                        anchor = add3(rotate(jp, quat), pos);
+                        axis = rotate(jax, quat);
+                        const float d = qe[ad] - aj_q0[j];
+                        pos = {pos.x + axis.x * d, pos.y + axis.y * d, pos.z + axis.z * d};
+                    } else {  // ball
+                        anchor = add3(rotate(jp, quat), pos);
+                        axis = rotate(jax, quat);
+                        if (H.has_ball) st4(jq + 4 * j, quat);
+                        float n;
+                        const Q4 qloc = normalize4(ld4(qe + ad), &n);
+                        st4(qe + ad, qloc);
+                        jn[j] = n;
+                        quat = qmul(quat, qloc);
+                        pos = sub3(anchor, rotate(jp, quat));
+                    }
+                    st3(ja + 6 * j, anchor);
+                    st3(ja + 6 * j + 3, axis);
+                }
+                st3(bx + (s + 1) * 7, pos);
+                st4(bx + (s + 1) * 7 + 3, quat);
+            }
+            wave_sync();
+        }
+
+        // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
+        const V3 cref = ld3(bx + 7);  // slot 0 = first active body (the root): moments are taken about it
+        const bool trunk_w = (!a.single) && kind < 2;
+        for (int k = lg; k < K; k += G) {
+            const float *bp = bx + (site_slot[k] + 1) * 7;
+            const V3 sx = add3(ld3(bp), rotate(ld3(site_pos + 3 * k), ld4(bp + 3)));
+            float w0, w1, w2;
+            if (a.single) {
+                w0 = a.kpw3[3 * k] ? 1.f : 0.f; w1 = a.kpw3[3 * k + 1] ? 1.f : 0.f; w2 = a.kpw3[3 * k + 2] ? 1.f : 0.f;
+            } else {
+                w0 = w1 = w2 = (trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f);
+            }
+            const float rx = (kpl[3 * k] - sx.x) * w0, ry = (kpl[3 * k + 1] - sx.y) * w1, rz = (kpl[3 * k + 2] - sx.z) * w2;
+            const float term = (rx * rx + ry * ry) + rz * rz;
+            if (any_grad) {
+                const V3 f = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
+                const V3 tq = cross3(sub3(sx, cref), f);
+                st3(sw + 6 * k, f);
+                st3(sw + 6 * k + 3, tq);
+            }
+            r2[k] = term;
+        }
+        wave_sync();
+        float loss = 0.0f;
+        for (int k = 0; k < K; ++k) loss += r2[k];  // every lane: same order, broadcast LDS reads
+        wave_sync();
+
+        float gnew[NQR];
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
+        if (any_grad) {
+            // ---- subtree wrench sums, leaves to root (oracle: sites in id order, then children in
+            //      decreasing id order) --------------------------------------------------------------
+            for (int lev = H.nlev - 1; lev >= 0; --lev) {
+                const int s_end = lev_adr[lev + 1];
+                for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
+                    V3 Fs = {0.f, 0.f, 0.f}, Ts = {0.f, 0.f, 0.f};
+                    const int k0 = ab_sadr[s], k1 = k0 + ab_snum[s];
+                    for (int i = k0; i < k1; ++i) {
+                        const int k = site_list[i];
+                        Fs = add3(Fs, ld3(sw + 6 * k));
+                        Ts = add3(Ts, ld3(sw + 6 * k + 3));
+                    }
+                    const int c0 = ab_cadr[s], c1 = c0 + ab_cnum[s];
+                    for (int i = c0; i < c1; ++i) {
+                        const int c = child_list[i];
+                        Fs = add3(Fs, ld3(bw + 6 * c));
+                        Ts = add3(Ts, ld3(bw + 6 * c + 3));
+                    }
+                    st3(bw + 6 * s, Fs);
+                    st3(bw + 6 * s + 3, Ts);
+                }
+                wave_sync();
+            }
+            // gg aliases sw: all site wrenches have been consumed
+            for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
+            wave_sync();
+            // ---- per-joint gradient ---------------------------------------------------
+            for (int j = lg; j < H.naj; j += G) {
+                const int ty = aj_type[j], ad = aj_qadr[j], s = aj_slot[j];
+                const V3 Fs = ld3(bw + 6 * s), T0 = ld3(bw + 6 * s + 3);
+                const V3 anchor = ld3(ja + 6 * j), axis = ld3(ja + 6 * j + 3);
+                const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
+                if (ty == JHINGE) {
+                    gg[ad] = dot3(axis, tau);
+                } else if (ty == JSLIDE) {
+                    gg[ad] = dot3(axis, Fs);
+                } else {
+                    int qa = ad;
+                    V3 tl = tau;
+                    if (ty == JFREE) {
+                        st3(gg + ad, Fs);
+                        qa = ad + 3;
+                    } else {
+                        const Q4 pq = ld4(jq + 4 * j);
+                        tl = rotate(tau, Q4{pq.w, -pq.x, -pq.y, -pq.z});
+                    }
+                    const Q4 qh = ld4(qe + qa);
+                    const V3 u = {qh.x, qh.y, qh.z};
+                    const V3 uxt = cross3(u, tl);
+                    const float n = jn[j];
+                    const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
+                    gg[qa] = (-2.0f * dot3(tl, u)) / dn;
+                    gg[qa + 1] = (2.0f * (qh.w * tl.x - uxt.x)) / dn;
+                    gg[qa + 2] = (2.0f * (qh.w * tl.y - uxt.y)) / dn;
+                    gg[qa + 3] = (2.0f * (qh.w * tl.z - uxt.z)) / dn;
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                if (e < nq && ((mbits >> r) & 1u)) gnew[r] = gg[e];
+            }
+            wave_sync();
+        }
+
+        // ---- solver transitions (jaxopt ProjectedGradient) ------------------------------------
+        if (st_in == ST_VG_Y) {
+            fy = loss;
+            eta = stepsize;
+            nls = 0;
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                g[r] = gnew[r];
+                if (e < nq) cand[r] = clipf(y[r] - eta * g[r], lbv[e], ubv[e]);
+            }
+            c_grad++; s_grad++;
+            st = ST_LS;
+        } else if (st_in == ST_LS) {
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                if (e < nq) {
+                    const float d = cand[r] - y[r];
+                    red[e] = d * d;
+                    red[nqpad + e] = d * g[r];
+                }
+            }
+        } else if (st_in == ST_VG_X) {
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                if (e < nq) {
+                    const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
+                    red[e] = d * d;
+                }
+            }
+        }
+        wave_sync();
+        float sum0 = 0.0f, sum1 = 0.0f;
+        if (st_in == ST_LS) {
+            for (int e = 0; e < nq; ++e) { sum0 += red[e]; sum1 += red[nqpad + e]; }
+        } else if (st_in == ST_VG_X) {
+            for (int e = 0; e < nq; ++e) sum0 += red[e];
+        }
+        wave_sync();
+
+        bool ending = false;
+        if (st_in == ST_LS) {
+            c_ls++; s_ls++;
+            const float lhs = eta * (loss - fy);
+            const float rhs = eta * sum1 + 0.5f * sum0 + eps;
+            bool accept = !(lhs > rhs);
+            if (!accept) {
+                eta = eta * 0.5f;
+                nls++;
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    if (e < nq) cand[r] = clipf(y[r] - eta * g[r], lbv[e], ubv[e]);
+                }
+                if (nls >= a.maxls) accept = true;
+            }
+            if (accept) {
+                next_step = (eta <= 1e-6f) ? 1.0f : eta / 0.5f;
+                tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
+                const float beta = (t - 1.0f) / tn;
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const float d = cand[r] - x[r];
+                    y[r] = cand[r] + beta * d;
+                    x[r] = cand[r];
+                }
+                st = ST_VG_X;
+            }
+        } else if (st_in == ST_VG_X) {
+            fx = loss;
+            error = __builtin_sqrtf(sum0);
+            stepsize = next_step;
+            t = tn;
+            iter++;
+            c_grad++; s_grad++;
+            if (error > a.tol && iter < a.maxiter) st = ST_VG_Y;
+            else ending = true;
+        }
+
+        // ---- end of a solve: replace_qs (utils.py:147-169), next solve / next frame ------------------------
+        if (__any(ending)) {
+            if (ending) {
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    if (e < nq) {
+                        const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
+                        // full-body solve: qpos <- params; root / part solves: make_qs(q0, mask, params)
+                        const bool blend = a.single ? false : (kind != 2);
+                        qe[e] = blend ? ((1.0f - mi) * q0[r] + mi * x[r]) : x[r];
+                    }
+                }
+            }
+            wave_sync();
+            if (ending && !a.single) {  // kinematics normalises quaternions in qpos
+                for (int qi = lg; qi < H.nquat; qi += G) {
+                    const int ad = quat_adr[qi];
+                    float n;
+                    st4(qe + ad, normalize4(ld4(qe + ad), &n));
+                }
+            }
+            wave_sync();
+            if (ending) {
+                c_iter += iter;
+                c_solves++;
+                if (a.single) {
+                    for (int e = lg; e < nq; e += G) a.qpos_out[(size_t)chain * nq + e] = qe[e];
+                    if (lg == 0) {
+                        float *so = a.err_out + (size_t)chain * 4;
+                        so[0] = error; so[1] = stepsize; so[2] = t; so[3] = fx;
+                        if (a.counters_out) {
+                            uint32_t *co = a.counters_out + (size_t)chain * 4;
+                            co[0] = (uint32_t)iter; co[1] = s_ls; co[2] = s_grad; co[3] = 1u;
+                        }
+                    }
+                    st = ST_DONE;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NQR; ++r) {
+                        const int e = r * G + lg;
+                        if (e < nq) q0[r] = qe[e];
+                    }
+                    if (kind < 2) {
+                        // root optimisation is not part of the frame's counters (compute_stac.py:17-104)
+                        c_iter = c_ls = c_grad = c_solves = 0;
+                    }
+                    kind++;
+                    if (kind > a.P + 2) {  // frame finished: record it (compute_stac.py:261-267)
+                        const size_t fo = (size_t)chain * a.F + frame;
+                        for (int e = lg; e < nq; e += G) a.qpos_out[fo * nq + e] = qe[e];
+                        if (lg == 0) {
+                            a.err_out[fo] = error;
+                            if (a.counters_out) {
+                                uint32_t *co = a.counters_out + fo * 4;
+                                co[0] = c_iter; co[1] = c_ls; co[2] = c_grad; co[3] = c_solves;
+                            }
+                        }
+                        c_iter = c_ls = c_grad = c_solves = 0;
+                        frame++;
+                        kind = 2;
+                        if (frame >= a.F) {
+                            if (a.q_carry_out)
+                                for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
+                            st = ST_DONE;
+                        } else {
+                            for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
+                        }
+                    } else if (kind < 2) {  // second root pass: seed the translation again (compute_stac.py:80-81)
+#pragma unroll
+                        for (int r = 0; r < NQR; ++r) {
+                            const int e = r * G + lg;
+                            if (e < 3) q0[r] = kpl[3 * a.root_kp_idx + e];
+                        }
+                    }
+                    if (st != ST_DONE) {
+#pragma unroll
+                        for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; }
+                        stepsize = 1.0f; t = 1.0f; iter = 0; s_ls = 0; s_grad = 0;
+                        error = __builtin_inff();
+                        st = ST_VG_Y;
+                    }
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone forward kinematics: one thread per pose, whole body tree (utils.kinematics)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, int N, float *qpos_norm_out,
+                                                 float *xpos, float *xquat, float *site_xpos) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *q = qpos + (size_t)n * M.nq;
+    float *xp = xpos + (size_t)n * M.nbody * 3;
+    float *xq = xquat + (size_t)n * M.nbody * 4;
+    float *qn = qpos_norm_out ? qpos_norm_out + (size_t)n * M.nq : nullptr;
+    if (qn) for (int i = 0; i < M.nq; ++i) qn[i] = q[i];
+    xp[0] = xp[1] = xp[2] = 0.f;
+    xq[0] = 1.f; xq[1] = xq[2] = xq[3] = 0.f;
+    for (int b = 1; b < M.nbody; ++b) {
+        const int p = M.body_parentid[b];
+        const Q4 pquat = ld4(xq + 4 * p);
+        V3 pos = add3(ld3(xp + 3 * p), rotate(ld3(M.body_pos + 3 * b), pquat));
+        Q4 quat = qmul(pquat, ld4(M.body_quat + 4 * b));
+        const int j0 = M.body_jntadr[b], j1 = j0 + M.body_jntnum[b];
+        for (int j = j0; j < j1; ++j) {
+            const int ty = M.jnt_type[j], ad = M.jnt_qposadr[j];
+            const V3 jp = ld3(M.jnt_pos + 3 * j), jax = ld3(M.jnt_axis + 3 * j);
+            if (ty == JFREE) {
+                pos = ld3(q + ad);
+                float nn;
+                quat = normalize4(ld4(q + ad + 3), &nn);
+                if (qn) st4(qn + ad + 3, quat);
+            } else if (ty == JHINGE) {
+                const V3 anchor = add3(rotate(jp, quat), pos);
+                float sn, cs;
+                sincos_((q[ad] - M.qpos0[ad]) * 0.5f, &sn, &cs);
+                quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
+                pos = sub3(anchor, rotate(jp, quat));
+            } else if (ty == JSLIDE) {
+                const V3 axis = rotate(jax, quat);
+                const float d = q[ad] - M.qpos0[ad];
+                pos = {pos.x + axis.x * d, pos.y + axis.y * d, pos.z + axis.z * d};
+            } else {
+                const V3 anchor = add3(rotate(jp, quat), pos);
+                float nn;
+                const Q4 qloc = normalize4(ld4(q + ad), &nn);
+                if (qn) st4(qn + ad, qloc);
+                quat = qmul(quat, qloc);
+                pos = sub3(anchor, rotate(jp, quat));
+            }
+        }
+        st3(xp + 3 * b, pos);
+        st4(xq + 4 * b, quat);
+    }
+    if (site_xpos) {
+        for (int k = 0; k < M.K; ++k) {
+            const int b = M.site_bodyid[k];
+            st3(site_xpos + ((size_t)n * M.K + k) * 3,
+                add3(ld3(xp + 3 * b), rotate(ld3(M.site_pos + 3 * k), ld4(xq + 4 * b))));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// offset phase (_m_opt, stac_core.py:148-170)
+// ------------------------------------------------------------------------------------------------
+// per (frame, site): R^T z and |z|^2 ; contrib[t][3K+1] with the K-site subtotal of |z|^2 last.
+__global__ __launch_bounds__(64) void m_contrib_kernel(FullModel M, const float *kp, const float *xpos,
+                                                        const float *xquat, int T, float *contrib) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int K = M.K;
+    float *out = contrib + (size_t)t * (3 * K + 1);
+    float z2t = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const int b = M.site_bodyid[k];
+        const float *q = xquat + ((size_t)t * M.nbody + b) * 4;
+        const float q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+        const float q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+        const float q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+        const float m0 = q00 + q11 - q22 - q33, m1 = 2.0f * (q12 - q03), m2 = 2.0f * (q13 + q02);
+        const float m3 = 2.0f * (q12 + q03), m4 = q00 - q11 + q22 - q33, m5 = 2.0f * (q23 - q01);
+        const float m6 = 2.0f * (q13 - q02), m7 = 2.0f * (q23 + q01), m8 = q00 - q11 - q22 + q33;
+        const float *p = xpos + ((size_t)t * M.nbody + b) * 3;
+        const float *yk = kp + (size_t)t * 3 * K + 3 * k;
+        const float z0 = yk[0] - p[0], z1 = yk[1] - p[1], z2 = yk[2] - p[2];
+        out[3 * k + 0] = m0 * z0 + m3 * z1 + m6 * z2;
+        out[3 * k + 1] = m1 * z0 + m4 * z1 + m7 * z2;
+        out[3 * k + 2] = m2 * z0 + m5 * z1 + m8 * z2;
+        z2t += z0 * z0 + z1 * z1 + z2 * z2;
+    }
+    out[3 * K] = z2t;
+}
+
+// partial[c] = sum over frames in index order (one thread per component), partial[3K+1] = T
+__global__ __launch_bounds__(128) void m_reduce_kernel(const float *contrib, int T, int K, float *partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = 3 * K + 1;
+    if (c < W) {
+        float s = 0.0f;
+        for (int t = 0; t < T; ++t) s += contrib[(size_t)t * W + c];
+        partial[c] = s;
+    } else if (c == W) {
+        partial[W] = (float)T;
+    }
+}
+
+// closed form; one thread (3K terms, scalar reductions in index order like the oracle)
+__global__ void m_finish_kernel(int K, const float *partial, const float *m0, const float *dreg, float lam,
+                                float *out, float *err) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float T = partial[3 * K + 1], z2 = partial[3 * K];
+    float ms = 0.0f, mm = 0.0f, reg = 0.0f;
+    for (int i = 0; i < 3 * K; ++i) {
+        const float d = dreg[i], s = partial[i], m0i = m0[i];
+        const float denom = T + lam * d;
+        const float numer = s + lam * d * m0i;
+        const float v = numer / denom;
+        out[i] = v;
+        ms += v * s;
+        mm += v * v;
+        const float dr = d * (v - m0i);
+        reg += dr * dr;
+    }
+    if (err) *err = ((z2 - 2.0f * ms) + T * mm) + lam * reg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from stac_abi.hip)
+// ------------------------------------------------------------------------------------------------
+template <int G, int NQR>
+static hipError_t launch_q(const QArgs &a, size_t lds_bytes, hipStream_t s) {
+    constexpr int CPW = 64 / G;
+    const int blocks = (a.C + CPW - 1) / CPW;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((q_phase_kernel<G, NQR>), dim3(blocks), dim3(64), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+// nq capacity of an instantiation is G*NQR.
+hipError_t launch_q_phase(const QArgs &a, int G, size_t lds_bytes, hipStream_t s, int *capacity_out) {
+    const int nq = a.h.nq;
+    *capacity_out = 0;
+#define STAC_TRY(GG, RR)                                   \
+    if (G == GG && nq <= GG * RR) {                        \
+        *capacity_out = GG * RR;                           \
+        return launch_q<GG, RR>(a, lds_bytes, s);          \
+    }
+    STAC_TRY(4, 20) STAC_TRY(4, 32)
+    STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)
+    STAC_TRY(16, 5) STAC_TRY(16, 8) STAC_TRY(16, 16)
+    STAC_TRY(32, 3) STAC_TRY(32, 4) STAC_TRY(32, 8)
+    STAC_TRY(64, 2) STAC_TRY(64, 4)
+#undef STAC_TRY
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
+                     float *site_xpos, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fk_kernel, dim3((N + 63) / 64), dim3(64), 0, s, M, qpos, N, qn, xpos, xquat, site_xpos);
+    return hipGetLastError();
+}
+
+hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
+                            float *contrib, float *partial, hipStream_t s) {
+    hipLaunchKernelGGL(m_contrib_kernel, dim3((T + 63) / 64), dim3(64), 0, s, M, kp, xpos, xquat, T, contrib);
+    const int W = 3 * M.K + 2;
+    hipLaunchKernelGGL(m_reduce_kernel, dim3((W + 127) / 128), dim3(128), 0, s, contrib, T, M.K, partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_m_finish(int K, const float *partial, const float *m0, const float *dreg, float lam, float *out,
+                           float *err, hipStream_t s) {
+    hipLaunchKernelGGL(m_finish_kernel, dim3(1), dim3(1), 0, s, K, partial, m0, dreg, lam, out, err);
+    return hipGetLastError();
+}
+
+}  // namespace stac

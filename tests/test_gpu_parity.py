@@ -1,0 +1,310 @@
+"""HIP path vs CPU oracle -- the parity tests proper (need a real MI355X: `-m gpu`).
+
+Everything goes through the C ABI (`libstac_hip.so`) via `stac_mjx_amd.engine.Engine`.
+Tolerances: the north star asks for qpos / offsets within 1e-4 of the reference.  The kernels are
+built to reproduce the float32 oracle operation for operation, so these tests assert EXACT equality
+(`assert_array_equal`, tolerance 0) wherever the oracle is defined, which implies the 1e-4 bar;
+`TOL_NORTH_STAR` is used only where two different algorithms are compared (golden FK vectors).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_NORTH_STAR = 1e-4  # BASELINE.json north_star: "within 1e-4"
+TOL_FK_GOLDEN = 5e-7   # stored reference output vs restated FK (float32 epsilon level)
+
+
+def _engine(fs, **kw):
+    from stac_mjx_amd.engine import Engine
+
+    return Engine(fs.tables, fs.lb, fs.ub, **kw)
+
+
+def _oracle(fs, **kw):
+    from oracle import Oracle
+
+    return Oracle(fs.tables, **kw)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- FK ------------------------------------------------------------------------------------------------
+def test_fk_bit_exact_and_golden(rodent_setup_legacy, demo_viz):
+    fs = rodent_setup_legacy
+    eng, orc = _engine(fs), _oracle(fs)
+    eng.set_site_pos(demo_viz["offsets"])
+    orc.set_site_pos(demo_viz["offsets"])
+    out = eng.fk(demo_viz["qpos"])
+    xpos, xquat, sx, qn = (_np(out[k]) for k in ("xpos", "xquat", "site_xpos", "qpos"))
+    assert np.abs(xpos - demo_viz["xpos"]).max() <= TOL_FK_GOLDEN
+    assert np.abs(sx - demo_viz["walker_body_sites"]).max() <= TOL_FK_GOLDEN
+    for f in range(50):
+        r = orc.fk(demo_viz["qpos"][f])
+        np.testing.assert_array_equal(xpos[f], r["xpos"])
+        np.testing.assert_array_equal(xquat[f], r["xquat"])
+        np.testing.assert_array_equal(sx[f], r["site_xpos"])
+        np.testing.assert_array_equal(qn[f], r["qpos"])
+
+
+def test_fk_random_poses_non_unit_quaternions(rodent_setup):
+    fs = rodent_setup
+    eng, orc = _engine(fs), _oracle(fs)
+    rng = np.random.default_rng(5)
+    q = fs.tables.qpos0[None] + rng.normal(0, 0.4, (33, 74)).astype(np.float32)
+    out = eng.fk(q)
+    for f in range(33):
+        r = orc.fk(q[f])
+        np.testing.assert_array_equal(_np(out["xpos"][f]), r["xpos"])
+        np.testing.assert_array_equal(_np(out["xquat"][f]), r["xquat"])
+        np.testing.assert_array_equal(_np(out["qpos"][f]), r["qpos"])
+
+
+# ---- single solves (the StacCore.q_opt seam) ------------------------------------------------------------
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
+@pytest.mark.parametrize("which", ["all", "part", "root_trunk"])
+def test_q_solve_bit_exact(rodent_setup, rodent_mocap, lanes, which):
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=lanes), _oracle(fs)
+    N = 5
+    kp = rodent_mocap[100:100 + N]
+    q0 = np.repeat(fs.tables.qpos0[None], N, 0)
+    q0[:, :3] = kp[:, 3 * fs.root_kp_idx: 3 * fs.root_kp_idx + 3]
+    if which == "all":
+        qs, ks = np.ones(74, bool), np.ones(69, bool)
+    elif which == "part":
+        qs, ks = fs.part_masks[1], np.ones(69, bool)
+    else:
+        qs, ks = np.arange(74) < 7, np.repeat(fs.trunk_kps, 3)
+    params, state, counters = eng.q_solve(kp, q0, qs, ks)
+    params, state, counters = _np(params), _np(state), _np(counters)
+    for n in range(N):
+        x, st = orc.q_opt(kp[n], qs, ks, q0[n], fs.lb, fs.ub)
+        assert counters[n].tolist() == [st["iter_num"], st["ls_evals"], st["grad_evals"], 1]
+        np.testing.assert_array_equal(params[n], x)
+        np.testing.assert_array_equal(state[n], np.array([st["error"], st["stepsize"], st["t"], st["loss"]], np.float32))
+        assert np.abs(params[n] - x).max() <= TOL_NORTH_STAR
+
+
+# ---- the q_phase drivers ---------------------------------------------------------------------------------
+def _compare_phase(res, ref, bodies=True):
+    np.testing.assert_array_equal(_np(res["counters"]).astype(np.uint32), ref["counters"])
+    np.testing.assert_array_equal(_np(res["qpos"]), ref["qpos"])
+    np.testing.assert_array_equal(_np(res["frame_error"]), ref["frame_error"])
+    np.testing.assert_array_equal(_np(res["marker_sites"]), ref["marker_sites"])
+    if bodies:
+        np.testing.assert_array_equal(_np(res["xpos"]), ref["xpos"])
+        np.testing.assert_array_equal(_np(res["xquat"]), ref["xquat"])
+    assert np.abs(_np(res["qpos"]) - ref["qpos"]).max() <= TOL_NORTH_STAR
+
+
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
+def test_q_phase_ik_clips_bit_exact(rodent_setup, rodent_mocap, lanes):
+    """Stac.ik_only semantics: root optimisation on frame 0 of every clip, then warm-started frames."""
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=lanes), _oracle(fs)
+    kp = rodent_mocap[:9 * 3].reshape(9, 3, 69)  # 9 clips (ragged vs lanes), 3 frames
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(res, ref)
+    np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
+
+
+def test_q_phase_carried_chain_no_root_opt(rodent_setup, rodent_mocap):
+    """fit_offsets semantics: one chain continued across calls with q_init (stac.py:298-311)."""
+    fs = rodent_setup
+    eng, orc = _engine(fs), _oracle(fs)
+    kp = rodent_mocap[:4]
+    q, _ = orc.root_optimization(kp, fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
+    ref1 = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
+    ref2 = orc.pose_optimization(kp, ref1["carry_qpos"], fs.lb, fs.ub, fs.part_masks)
+    r1 = eng.q_phase(kp[None], part_masks=fs.part_masks, q_init=q[None])
+    r2 = eng.q_phase(kp[None], part_masks=fs.part_masks, q_init=r1["carry_qpos"])
+    np.testing.assert_array_equal(_np(r1["qpos"][0]), ref1["qpos"])
+    np.testing.assert_array_equal(_np(r2["qpos"][0]), ref2["qpos"])
+    np.testing.assert_array_equal(_np(r2["frame_error"][0]), ref2["frame_error"])
+    np.testing.assert_array_equal(_np(r2["xquat"][0]), ref2["xquat"])
+
+
+def test_q_phase_no_parts_and_tight_iteration_cap(rodent_setup, rodent_mocap):
+    fs = rodent_setup
+    eng, orc = _engine(fs, maxiter=7, tol=1e-9), _oracle(fs, maxiter=7, tol=1e-9)
+    kp = rodent_mocap[200:206].reshape(3, 2, 69)
+    res = eng.q_phase(kp, part_masks=[], trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, do_root_opt=True)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, [], fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(res, ref)
+    assert (ref["counters"][..., 0] == 7).all()
+
+
+def test_q_phase_fruitfly_model(fly_setup):
+    """Different tree (quat-oriented bodies, nq=43, K=30, 6 part groups, no root optimisation)."""
+    fs = fly_setup
+    eng, orc = _engine(fs, tol=5e-3, maxiter=60), _oracle(fs, tol=5e-3, maxiter=60)
+    rng = np.random.default_rng(11)
+    qtrue = fs.tables.qpos0[None] + np.clip(rng.normal(0, 0.15, (6, 43)), -0.3, 0.3).astype(np.float32)
+    qtrue[:, 3:7] = fs.tables.qpos0[3:7]
+    kp = np.stack([orc.fk(q)["site_xpos"].reshape(-1) for q in qtrue]).reshape(3, 2, 90)
+    kp = kp + rng.normal(0, 1e-3, kp.shape).astype(np.float32)
+    res = eng.q_phase(kp, part_masks=fs.part_masks)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 0, 7, do_root_opt=False)
+    _compare_phase(res, ref)
+
+
+def test_q_phase_ball_and_slide_joints():
+    from stac_mjx_amd.fit_model import FitSetup
+    from stac_mjx_amd.mjcf import align_joint_dims, compile_mjcf
+
+    xml = """
+    <mujoco><compiler angle="radian"/><worldbody>
+      <body name="r" pos="0 0 0.5"><freejoint/>
+        <site name="s0" pos="0.1 0 0"/><site name="s0b" pos="0 0.1 0.05"/>
+        <body name="a" pos="0.2 0 0" quat="0.9 0.1 0.2 0.3"><joint name="ball" type="ball" pos="0.01 0.02 0"/>
+          <site name="s1" pos="0 0.1 0"/><site name="s1b" pos="0.1 0.1 0"/>
+          <body name="b" pos="0 0.2 0"><joint name="sl" type="slide" axis="1 1 0" range="-0.2 0.2"/>
+            <joint name="h" axis="0 1 1" pos="0 0 .1" range="-1 1"/>
+            <site name="s2" pos="0.05 0.02 0.1"/><site name="s2b" pos="-0.05 0.1 0"/></body></body></body>
+    </worldbody></mujoco>"""
+    t = compile_mjcf(xml, from_string=True)
+    lb, ub, names = align_joint_dims(t.jnt_type, t.jnt_range, t.jnt_names)
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    eng, orc = Engine(t, lb, ub, tol=1e-5, maxiter=80), Oracle(t, tol=1e-5, maxiter=80)
+    rng = np.random.default_rng(2)
+    qt = t.qpos0[None] + rng.normal(0, 0.1, (4, t.nq)).astype(np.float32)
+    kp = np.stack([orc.fk(q)["site_xpos"].reshape(-1) for q in qt]).reshape(2, 2, 18)
+    pm = np.zeros((1, t.nq), bool)
+    pm[0, 7:] = True
+    res = eng.q_phase(kp, part_masks=pm)
+    ref = orc.ik_clips(kp, lb, ub, pm, np.ones(6, bool), 0, 7, do_root_opt=False)
+    _compare_phase(res, ref)
+
+
+# ---- offset phase ----------------------------------------------------------------------------------------------
+def test_m_phase_bit_exact_and_partial_sums(rodent_setup_legacy, demo_viz):
+    fs = rodent_setup_legacy
+    eng, orc = _engine(fs), _oracle(fs)
+    eng.set_site_pos(demo_viz["offsets"])
+    orc.set_site_pos(demo_viz["offsets"])
+    q, kp, m0 = demo_viz["qpos"], demo_viz["kp_data"], demo_viz["offsets"]
+    part = eng.m_partial(kp, q)
+    np.testing.assert_array_equal(_np(part), orc.m_partial(kp, q))
+    off, err = eng.m_finish(part, m0, fs.is_regularized, 1.0)
+    ref_off, ref_err = orc.m_finish(orc.m_partial(kp, q), m0, fs.is_regularized, 1.0)
+    np.testing.assert_array_equal(_np(off), ref_off)
+    assert float(err) == np.float32(ref_err)
+    assert np.abs(_np(off) - ref_off).max() <= TOL_NORTH_STAR
+    # sharded partial sums (what the all-reduce adds up) reproduce the closed form to rounding
+    pa, pb = eng.m_partial(kp[:20], q[:20]), eng.m_partial(kp[20:], q[20:])
+    off2, _ = eng.m_finish(pa + pb, m0, fs.is_regularized, 1.0)
+    assert np.abs(_np(off2) - ref_off).max() <= 1e-6
+
+
+def test_m_opt_known_answers_through_hip(toy_tables):
+    """The reference's tests/unit/test_m_opt.py cases, run through the HIP path."""
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.mjcf import align_joint_dims
+
+    t = toy_tables
+    lb, ub, _ = align_joint_dims(t.jnt_type, t.jnt_range, t.jnt_names)
+    eng = Engine(t, lb, ub)
+    gt_a = np.array([[0.1, 0.2, 0.3], [0.4, 0.5, 0.6], [0.15, 0.25, 0.35]], np.float32)
+    gt_b = np.array([[0.2, -0.1, 0.4], [0.3, 0.4, -0.2], [-0.1, 0.3, 0.1]], np.float32)
+
+    def keypoints(q, off):
+        eng.set_site_pos(off)
+        return eng.fk(q, want=("site_xpos",))["site_xpos"].reshape(len(q), -1)
+
+    z = np.zeros((3, 3), np.float32)
+    q = np.zeros((5, 3), np.float32)
+    p, e = eng.m_opt(keypoints(q, gt_a), q, z, z, 0.0)
+    np.testing.assert_allclose(_np(p), gt_a, atol=1e-5)
+    assert float(e) < 1e-8
+    q = (np.random.RandomState(42).randn(10, 3) * 0.5).astype(np.float32)
+    p, _ = eng.m_opt(keypoints(q, gt_a), q, z, z, 0.0)
+    np.testing.assert_allclose(_np(p), gt_a, atol=1e-5)
+    q = np.zeros((8, 3), np.float32)
+    q[:, 0] = np.linspace(0.0, np.pi / 4, 8)
+    p, _ = eng.m_opt(keypoints(q, gt_b), q, gt_b, z, 0.0)
+    np.testing.assert_allclose(_np(p), gt_b, atol=1e-5)
+    q = (np.random.RandomState(99).randn(15, 3) * 1.5).astype(np.float32)
+    p, _ = eng.m_opt(keypoints(q, gt_b), q, z, z, 0.0)
+    np.testing.assert_allclose(_np(p), gt_b, atol=1e-4)
+    q = (np.random.RandomState(42).randn(10, 3) * 0.3).astype(np.float32)
+    kp = keypoints(q, gt_a)
+    p, _ = eng.m_opt(kp, q, np.full((3, 3), 99.0, np.float32), np.ones((3, 3), np.float32), 0.0)
+    np.testing.assert_allclose(_np(p), gt_a, atol=1e-5)
+    p, _ = eng.m_opt(kp, q, z, np.ones((3, 3), np.float32), 1e6)
+    np.testing.assert_allclose(_np(p), z, atol=1e-3)
+    q = np.zeros((10, 3), np.float32)
+    gt = np.full((3, 3), 0.5, np.float32)
+    kp = keypoints(q, gt)
+    is_reg = np.zeros((3, 3), np.float32)
+    is_reg[0] = 1.0
+    ps, _ = eng.m_opt(kp, q, z, is_reg, 1e4)
+    pn, _ = eng.m_opt(kp, q, z, is_reg, 0.0)
+    assert np.linalg.norm(_np(ps)[0]) < np.linalg.norm(_np(pn)[0])
+    np.testing.assert_allclose(_np(ps)[1:], gt[1:], atol=1e-5)
+
+
+def test_set_get_site_pos_roundtrip_and_effect(rodent_setup):
+    fs = rodent_setup
+    eng = _engine(fs)
+    np.testing.assert_array_equal(_np(eng.get_site_pos()), fs.tables.site_pos)
+    new = fs.tables.site_pos + 0.01
+    eng.set_site_pos(new)
+    np.testing.assert_array_equal(_np(eng.get_site_pos()), new)
+    a = _np(eng.fk(fs.tables.qpos0[None])["site_xpos"])
+    orc = _oracle(fs)
+    orc.set_site_pos(new)
+    np.testing.assert_array_equal(a[0], orc.fk(fs.tables.qpos0)["site_xpos"])
+
+
+# ---- size-independent properties at BASELINE sizes ----------------------------------------------------------------
+def test_full_size_properties_10k_frames(rodent_setup, rodent_mocap):
+    """BASELINE config 2 size (10 000 frames, independent chains): properties the domain offers."""
+    import torch
+
+    fs = rodent_setup
+    eng = _engine(fs)
+    kp = np.tile(rodent_mocap, (10, 1)).reshape(10000, 1, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      do_root_opt=True)
+    torch.cuda.synchronize()
+    q = _np(res["qpos"])[:, 0]
+    # (1) batch invariance / determinism: the 10 tiled copies of the same frame give identical bits
+    np.testing.assert_array_equal(q[:1000], q[9000:])
+    # (2) box constraints hold; root quaternion is unit after replace_qs
+    assert (q >= fs.lb - 1e-6).all() and (q <= fs.ub + 1e-6).all()
+    np.testing.assert_allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0, atol=1e-5)
+    # (3) joints that are not ancestors of any marker never move
+    orc = _oracle(fs)
+    qr = fs.tables.qpos0 + np.random.default_rng(3).normal(0, 0.1, 74).astype(np.float32)
+    _, g = orc.q_loss(qr, kp[0, 0], np.ones(74, bool), np.ones(69, bool), qr)
+    np.testing.assert_array_equal(q[:, g == 0], np.broadcast_to(fs.tables.qpos0[g == 0], (10000, 29)))
+    # (4) idempotence of the outputs: FK(qpos_out) == markers_out / xpos_out
+    fk = eng.fk(res["qpos"].reshape(-1, 74))
+    np.testing.assert_array_equal(_np(fk["site_xpos"]), _np(res["marker_sites"]).reshape(-1, 23, 3))
+    np.testing.assert_array_equal(_np(fk["xpos"]), _np(res["xpos"]).reshape(-1, 67, 3))
+    # (5) a sample of frames agrees bit for bit with the oracle
+    idx = [0, 123, 999]
+    ref = orc.ik_clips(kp[idx], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    np.testing.assert_array_equal(q[idx], ref["qpos"][:, 0])
+    # (6) the fit explains the markers (initial offsets -> cm-level residual, like the oracle)
+    err = np.linalg.norm(_np(res["marker_sites"])[:, 0] - kp[:, 0].reshape(-1, 23, 3), axis=-1)
+    assert err.mean() < 2e-2
+
+
+def test_errors_are_loud(rodent_setup):
+    from stac_mjx_amd.engine import StacHipError
+
+    fs = rodent_setup
+    eng = _engine(fs, maxiter=0)
+    with pytest.raises(StacHipError):
+        eng.q_phase(np.zeros((1, 1, 69), np.float32), part_masks=[])
+    with pytest.raises(ValueError):
+        _engine(fs).q_phase(np.zeros((1, 1, 68), np.float32), part_masks=[])
