@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the STAC q_phase on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path (`stac_q_phase`: root optimisation + full-body solve + part
+solves per frame, PG parity mode, FTOL/N_ITER_Q of configs/model/rodent.yaml) over one batch of
+synthetic keypoints that is already resident in HBM.  Workload = BASELINE.json configs[1]: rodent,
+23 keypoints, 10 000 synthetic frames, q_phase only, on every GPU (weak scaling: clips are
+independent, each rank fits its own shard; no collective on the data path).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 10000] [--frames-per-clip 1]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL only for the timing barrier).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def load_setup():
+    from stac_mjx_amd.fit_model import finish_fit_setup
+    from stac_mjx_amd.mjcf import ModelTables
+
+    g = ROOT / "tests" / "golden"
+    cfg = json.load(open(g / "rodent_model_cfg.json"))
+    fs = finish_fit_setup(ModelTables.load(g / "rodent_tables.npz"), cfg, list(cfg["KEYPOINT_MODEL_PAIRS"].keys()))
+    return fs, cfg
+
+
+def cpu_baseline(fs, cfg, kp_host, target_s=15.0):
+    """The oracle (CPU restatement, kind='port') on a bounded sample of the same workload."""
+    from oracle import Oracle
+
+    orc = Oracle(fs.tables, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]))
+    cores = orc.max_threads()
+    C, F = kp_host.shape[0], kp_host.shape[1]
+
+    def run(n):
+        t0 = time.perf_counter()
+        orc.ik_clips(kp_host[:n], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims,
+                     do_root_opt=True, want_bodies=False)
+        return time.perf_counter() - t0
+
+    n0 = min(C, max(cores * 2, 1))
+    t0 = run(n0)
+    n = int(min(C, max(n0, n0 * target_s / max(t0, 1e-3))))
+    t = run(n)
+    return {"value": n * F / t, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/stac_oracle.c (f32 PG restatement, OpenMP over clips) on the first {n} clips x {F} frames "
+                      f"of the same synthetic batch, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step")
+    ap.add_argument("--frames-per-clip", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.synth import synth_keypoints, synth_offsets
+
+    fs, cfg = load_setup()
+    F = args.frames_per_clip
+    C = args.frames // F
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), lanes_per_chain=args.lanes,
+                 device=f"cuda:{local_rank}")
+    # synthetic batch (seeded per rank), generated with the engine's own FK, then offsets fixed
+    eng.set_site_pos(synth_offsets(fs))
+    fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
+    kp_host, _ = synth_keypoints(fs, fk, C, F, seed=1000 * rank, noise_seed=1000 * rank + 1)
+    kp = torch.as_tensor(kp_host).to(eng.device)
+    out = None
+
+    def step():
+        nonlocal out
+        out = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                          root_dims=fs.root_dims, do_root_opt=True, want_bodies=False, want_markers=False, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()  # same stream the kernel is launched on (torch's current stream)
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    frames_step = C * F
+    value = world * frames_step * args.steps / elapsed
+    cnt = out["counters"].to(torch.float64).sum(dim=(0, 1)).cpu().numpy()
+    err = torch.linalg.norm((eng.fk(out["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
+                             - kp.reshape(-1, fs.tables.nsite, 3)), dim=-1)
+    # algorithmic bytes of the q_phase kernel: keypoints in, qpos + residual out (576 B/frame)
+    bytes_frame = 12 * fs.tables.nsite + 4 * fs.tables.nq + 4
+    achieved = frames_step * bytes_frame / (kern_ms * 1e-3) / 1e9
+    # algorithmic flops (full-tree constants): value+grad 17.9 kflop, loss 15.9 kflop
+    flops = cnt[2] * 17.9e3 + cnt[1] * 15.9e3
+    line = {
+        "metric": "frames/sec STAC pose-fit (rodent, 23 kp)", "value": value, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[1]: rodent.xml, 23 keypoints, {frames_step} synthetic frames per GPU, "
+                        f"q_phase only (root opt + full + 5 part PG solves per frame), n_frames_per_clip={F} "
+                        f"({C} independent chains), FTOL={cfg['FTOL']}, N_ITER_Q={cfg['N_ITER_Q']}, solver=pg (parity mode)",
+            "frames_per_gpu": frames_step, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
+            "parallelism": f"clips sharded over {world} GPU(s), no data-path collective",
+            "iters_per_frame": cnt[0] / frames_step, "ls_evals_per_frame": cnt[1] / frames_step,
+            "grad_evals_per_frame": cnt[2] / frames_step,
+            "marker_rmse_mm": float(torch.sqrt((err ** 2).mean()).item() * 1e3),
+            "valu_tflops_algorithmic": flops / (kern_ms * 1e-3) / 1e12,
+            "valu_frac_of_fp32_peak": flops / (kern_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "stac::q_phase_kernel",
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": bytes_frame},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(fs, cfg, kp_host)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@
 namespace stac {
 hipError_t launch_q_phase(const QArgs &a, int G, size_t lds_bytes, hipStream_t s, int *capacity_out);
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
-                     float *site_xpos, hipStream_t s);
+                     float *site_xpos, int normalize, hipStream_t s);
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
                             float *contrib, float *partial, hipStream_t s);
 hipError_t launch_m_finish(int K, const float *partial, const float *m0, const float *dreg, float lam, float *out,
@@ -312,8 +312,8 @@ extern "C" int32_t stac_get_site_pos(const stac_model *m, float *out, void *stre
     return STAC_OK;
 }
 
-extern "C" int32_t stac_fk(const stac_model *mc, const float *qpos, int32_t N, float *qn, float *xpos,
-                           float *xquat, float *site_xpos, void *stream) {
+static int fk_impl(const stac_model *mc, const float *qpos, int32_t N, float *qn, float *xpos, float *xquat,
+                   float *site_xpos, int normalize, void *stream) {
     stac_model *m = const_cast<stac_model *>(mc);
     if (!m || !qpos || N < 0) return fail(STAC_ERR_INVALID, "stac_fk: bad argument");
     if (N == 0) return STAC_OK;
@@ -324,8 +324,13 @@ extern "C" int32_t stac_fk(const stac_model *mc, const float *qpos, int32_t N, f
         if (!xpos) xpos = m->d_scratch;
         if (!xquat) xquat = m->d_scratch + (size_t)N * nb * 3;
     }
-    HIP_TRY(launch_fk(m->full(), qpos, N, qn, xpos, xquat, site_xpos, (hipStream_t)stream));
+    HIP_TRY(launch_fk(m->full(), qpos, N, qn, xpos, xquat, site_xpos, normalize, (hipStream_t)stream));
     return STAC_OK;
+}
+
+extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, float *qn, float *xpos,
+                           float *xquat, float *site_xpos, void *stream) {
+    return fk_impl(m, qpos, N, qn, xpos, xquat, site_xpos, 1, stream);
 }
 
 static int pick_lanes(const stac_model *m, int requested, int nchains) {
@@ -426,7 +431,8 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     const int rc = run_q(m, p, a, C, s);
     if (rc != STAC_OK) return rc;
     if (xpos_out || xquat_out || markers_out)
-        return stac_fk(m, qpos_out, C * F, nullptr, xpos_out, xquat_out, markers_out, stream);
+        // qpos_out already holds kinematics' normalised quaternions: use them as they are
+        return fk_impl(m, qpos_out, C * F, nullptr, xpos_out, xquat_out, markers_out, 0, stream);
     return STAC_OK;
 }
 
@@ -441,7 +447,7 @@ extern "C" int32_t stac_m_phase_partial(const stac_model *m, const float *kp, co
     hipStream_t s = (hipStream_t)stream;
     const size_t nb = m->h.nbody;
     float *xpos = workspace, *xquat = workspace + (size_t)T * nb * 3, *contrib = workspace + (size_t)T * nb * 7;
-    if (T > 0) HIP_TRY(launch_fk(m->full(), q, T, nullptr, xpos, xquat, nullptr, s));
+    if (T > 0) HIP_TRY(launch_fk(m->full(), q, T, nullptr, xpos, xquat, nullptr, 1, s));
     HIP_TRY(launch_m_partial(m->full(), kp, xpos, xquat, T, contrib, partial, s));
     return STAC_OK;
 }

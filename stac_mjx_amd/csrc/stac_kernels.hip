@@ -532,8 +532,10 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
 // ------------------------------------------------------------------------------------------------
 // stand-alone forward kinematics: one thread per pose, whole body tree (utils.kinematics)
 // ------------------------------------------------------------------------------------------------
+// normalize = 0: quaternions in qpos are used as they are (the q_phase kernel has already applied
+// kinematics' write-back normalisation; MJX's xquat IS that stored quaternion).
 __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, int N, float *qpos_norm_out,
-                                                 float *xpos, float *xquat, float *site_xpos) {
+                                                 float *xpos, float *xquat, float *site_xpos, int normalize) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float *q = qpos + (size_t)n * M.nq;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, 
             if (ty == JFREE) {
                 pos = ld3(q + ad);
                 float nn;
-                quat = normalize4(ld4(q + ad + 3), &nn);
+                quat = normalize ? normalize4(ld4(q + ad + 3), &nn) : ld4(q + ad + 3);
                 if (qn) st4(qn + ad + 3, quat);
             } else if (ty == JHINGE) {
                 const V3 anchor = add3(rotate(jp, quat), pos);
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, 
             } else {
                 const V3 anchor = add3(rotate(jp, quat), pos);
                 float nn;
-                const Q4 qloc = normalize4(ld4(q + ad), &nn);
+                const Q4 qloc = normalize ? normalize4(ld4(q + ad), &nn) : ld4(q + ad);
                 if (qn) st4(qn + ad, qloc);
                 quat = qmul(quat, qloc);
                 pos = sub3(anchor, rotate(jp, quat));
@@ -685,9 +687,9 @@ hipError_t launch_q_phase(const QArgs &a, int G, size_t lds_bytes, hipStream_t s
 }
 
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
-                     float *site_xpos, hipStream_t s) {
+                     float *site_xpos, int normalize, hipStream_t s) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fk_kernel, dim3((N + 63) / 64), dim3(64), 0, s, M, qpos, N, qn, xpos, xquat, site_xpos);
+    hipLaunchKernelGGL(fk_kernel, dim3((N + 63) / 64), dim3(64), 0, s, M, qpos, N, qn, xpos, xquat, site_xpos, normalize);
     return hipGetLastError();
 }
 

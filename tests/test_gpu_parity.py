@@ -287,9 +287,10 @@ def test_full_size_properties_10k_frames(rodent_setup, rodent_mocap):
     _, g = orc.q_loss(qr, kp[0, 0], np.ones(74, bool), np.ones(69, bool), qr)
     np.testing.assert_array_equal(q[:, g == 0], np.broadcast_to(fs.tables.qpos0[g == 0], (10000, 29)))
     # (4) idempotence of the outputs: FK(qpos_out) == markers_out / xpos_out
+    #     (stac_fk re-normalises the stored unit quaternion: allow the last ulp)
     fk = eng.fk(res["qpos"].reshape(-1, 74))
-    np.testing.assert_array_equal(_np(fk["site_xpos"]), _np(res["marker_sites"]).reshape(-1, 23, 3))
-    np.testing.assert_array_equal(_np(fk["xpos"]), _np(res["xpos"]).reshape(-1, 67, 3))
+    np.testing.assert_allclose(_np(fk["site_xpos"]), _np(res["marker_sites"]).reshape(-1, 23, 3), atol=3e-7, rtol=0)
+    np.testing.assert_allclose(_np(fk["xpos"]), _np(res["xpos"]).reshape(-1, 67, 3), atol=3e-7, rtol=0)
     # (5) a sample of frames agrees bit for bit with the oracle
     idx = [0, 123, 999]
     ref = orc.ik_clips(kp[idx], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
