@@ -1,0 +1,67 @@
+"""User-level pipeline with the reference's signatures (``stac_mjx/main.py``)."""
+
+from __future__ import annotations
+
+import time
+from pathlib import Path
+
+import numpy as np
+
+from . import io, utils
+from .config import compose_config
+from .stac import Stac
+
+
+def load_configs(config_dir, config_name: str = "config"):
+    """``stac_mjx.main.load_configs`` (main.py:18-30)."""
+    cfg = compose_config(config_dir, config_name=config_name)
+    print("Config loaded and validated.")
+    return cfg
+
+
+def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None):
+    """``stac_mjx.main.run_stac`` (main.py:33-139): fit_offsets (unless skipped) then ik_only (unless skipped).
+
+    Returns ``(fit_offsets_path, ik_only_path or None)``.  Raises ``ValueError`` when ``kp_data`` columns
+    do not match ``3 * len(kp_names)`` or ``n_frames_per_clip`` does not divide the frame count.
+    ``infer_qvels`` (post-processing) is not part of the hot path and is left empty.
+    """
+    base_path = Path.cwd() if base_path is None else Path(base_path)
+    kp_data = np.asarray(kp_data)
+    expected_cols = len(kp_names) * 3
+    if kp_data.shape[1] != expected_cols:
+        raise ValueError(
+            f"kp_data has {kp_data.shape[1]} columns but expected {expected_cols} ({len(kp_names)} keypoints x 3). "
+            "Ensure kp_data is shaped (n_frames, n_keypoints * 3) and that kp_names length matches the number of "
+            "keypoints in kp_data.")
+    start = time.time()
+    fit_offsets_path = base_path / cfg.stac.fit_offsets_path
+    ik_only_path = base_path / cfg.stac.ik_only_path
+    xml_path = base_path / cfg.model.MJCF_PATH
+    stac = Stac(xml_path, cfg, kp_names, setup=setup, device=device)
+
+    if not cfg.stac.skip_fit_offsets:
+        kps = kp_data[: cfg.stac.n_fit_frames]
+        print(f"Running fit. Mocap data shape: {kps.shape}")
+        fit_data = stac.fit_offsets(kps)
+        fit_offsets_path = io.save_data_to_h5(config=cfg, file_path=fit_offsets_path, **fit_data.as_dict())
+        print(f"saved fit to {fit_offsets_path}", flush=True)
+    else:
+        print("Skipping fit_offsets. To change this behavior, set cfg.stac.skip_fit_offsets to False.")
+
+    if cfg.stac.skip_ik_only:
+        print("Skipping IK-only phase. To change this behavior, set cfg.stac.skip_ik_only to False.")
+        return fit_offsets_path, None
+    if kp_data.shape[0] % cfg.stac.n_frames_per_clip != 0:
+        raise ValueError(
+            f"n_frames_per_clip ({cfg.stac.n_frames_per_clip}) must divide evenly with the total number of mocap "
+            f"frames({kp_data.shape[0]})")
+    print("Running ik_only()")
+    _, fit_data = io.load_stac_data(fit_offsets_path)
+    ik_data = stac.ik_only(kp_data, fit_data.offsets)
+    if cfg.stac.continuous:
+        ik_data = utils.handle_edge_effects(ik_data, cfg.stac.n_frames_per_clip)
+    print(f"Final qpos shape: {ik_data.qpos.shape}")
+    ik_only_path = io.save_data_to_h5(config=cfg, file_path=ik_only_path, **ik_data.as_dict())
+    print(f"Saved ik_only to {ik_only_path}. Finished in {(time.time() - start) / 60:.2f} minutes")
+    return fit_offsets_path, ik_only_path

@@ -1,0 +1,143 @@
+"""``Stac``: model set-up, ``fit_offsets`` / ``ik_only`` and output packing on the HIP engine.
+
+Mirrors the hot-path part of ``stac_mjx/stac.py`` (:91-503; rendering is out of scope).  The
+per-frame Python loops of the reference (``compute_stac.pose_optimization``) run inside one
+``stac_q_phase`` kernel launch per phase; sequencing, warm starts, sampling and packing follow the
+reference.
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import dist, prng, utils
+from .engine import Engine
+from .fit_model import FitSetup, build_fit_setup
+from .io import StacData
+from .stac_core import ModelHandle, StacCore
+
+
+class Stac:
+    """Skeletal registration on one GPU (or one rank of a multi-GPU job)."""
+
+    def __init__(self, xml_path, cfg, kp_names, *, setup: FitSetup | None = None, device=None, verbose: bool = True):
+        self.cfg = cfg
+        self._kp_names = list(kp_names)
+        self._xml_path = Path(xml_path) if xml_path is not None else None
+        self.verbose = verbose
+        self.setup = setup if setup is not None else build_fit_setup(self._xml_path, cfg.model, self._kp_names)
+        s = self.setup
+        self._lb, self._ub, self._part_names = s.lb, s.ub, s.part_names
+        self._indiv_parts = s.part_masks
+        self._trunk_kps = s.trunk_kps
+        self._root_kp_idx = s.root_kp_idx
+        self._is_regularized = s.is_regularized
+        self._body_names = s.tables.body_names
+        self._freejoint, self._slidejoint, self._fixed = s.freejoint, s.slidejoint, s.fixed_root
+        stac_cfg = cfg.stac
+        self.engine = Engine(s.tables, s.lb, s.ub, tol=float(cfg.model.FTOL), maxiter=int(cfg.model.N_ITER_Q),
+                             lanes_per_chain=int(stac_cfg.get("lanes_per_chain", 0) or 0), device=device)
+        self.stac_core_obj = StacCore(self.engine, float(cfg.model.FTOL), int(cfg.model.N_ITER_Q))
+        self._offsets = torch.as_tensor(s.tables.site_pos.copy())
+        self._timestep = s.tables.timestep
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _log(self, *a):
+        if self.verbose:
+            print(*a, flush=True)
+
+    def _model_handle(self):
+        return ModelHandle(engine=self.engine, nq=self.setup.tables.nq, jnt_type=self.setup.tables.jnt_type,
+                           site_pos=self.engine.get_site_pos())
+
+    def _get_error_stats(self, errors):
+        e = np.asarray(errors).reshape(-1)
+        return e, float(np.mean(e)), float(np.std(e))
+
+    def _q_phase(self, kp, *, do_root_opt, q_init=None, want_outputs=True):
+        s = self.setup
+        return self.engine.q_phase(
+            kp, part_masks=s.part_masks, trunk_kps=s.trunk_kps, root_kp_idx=max(s.root_kp_idx, 0),
+            root_dims=s.root_dims, do_root_opt=do_root_opt, q_init=q_init, want_bodies=want_outputs,
+            want_markers=want_outputs)
+
+    # -- fit_offsets (stac.py:253-354) ------------------------------------------------------------------
+    def fit_offsets(self, kp_data, time_indices=None) -> StacData:
+        """Alternate pose and offset optimisation on ONE warm-started chain over all frames.
+
+        ``time_indices`` (optional) overrides the PRNGKey(0) frame sample of the offset phase.
+        """
+        cfgm = self.cfg.model
+        eng = self.engine
+        kp = torch.as_tensor(np.asarray(kp_data, dtype=np.float32)).to(eng.device)
+        n = kp.shape[0]
+        self._offsets = eng.get_site_pos().clone()
+        do_root = self.setup.do_root_opt
+        if self._root_kp_idx == -1:
+            self._log("ROOT_OPTIMIZATION_KEYPOINT not specified, skipping Root Optimization.")
+        elif self._fixed:
+            self._log("ROOT_OPTIMIZATION_KEYPOINT specified but model has fixed root, skipping Root Optimization")
+        n_sample = int(cfgm.N_SAMPLE_FRAMES)
+        if time_indices is None:
+            time_indices = prng.sample_time_indices(n, n_sample, seed=0)
+        idx = torch.as_tensor(np.asarray(time_indices), dtype=torch.long, device=eng.device)
+        is_reg = torch.as_tensor(self._is_regularized).to(eng.device)
+        carry = None
+        res = None
+        for n_iter in range(int(cfgm.N_ITERS) + 1):
+            final = n_iter == int(cfgm.N_ITERS)
+            self._log("Final pose optimization" if final else f"Calibration iteration: {n_iter + 1}/{cfgm.N_ITERS}")
+            # root optimisation happens once, before the first pose pass (stac.py:277-296); the warm start is
+            # carried across iterations and into the final pass (stac.py:300-301,331-332)
+            res = self._q_phase(kp[None], do_root_opt=(do_root and n_iter == 0), q_init=carry, want_outputs=final)
+            carry = res["carry_qpos"]
+            _, mean, std = self._get_error_stats(res["frame_error"].cpu().numpy())
+            self._log(f"Mean: {mean}\nStandard deviation: {std}")
+            if final:
+                break
+            # offset phase (compute_stac.py:107-167): regularised toward the PREVIOUS iterate (stac.py:317-328)
+            partial = eng.m_partial(kp[idx], res["qpos"][0][idx])
+            partial = dist.all_reduce_partial(partial) if False else partial  # single chain: replicas only
+            new_off, err = eng.m_finish(partial, self._offsets, is_reg, float(cfgm.M_REG_COEF))
+            self._log(f"Final residual error of {float(err)}")
+            eng.set_site_pos(new_off)
+            self._offsets = new_off
+        return self._package_data(res, kp.cpu().numpy(), batched=False)
+
+    # -- ik_only (stac.py:356-454) --------------------------------------------------------------------------
+    def ik_only(self, kp_data, offsets) -> StacData:
+        """Inverse kinematics with fixed offsets; clips are independent chains, sharded over ranks."""
+        eng = self.engine
+        batched = utils.batch_kp_data(np.asarray(kp_data, dtype=np.float32), int(self.cfg.stac.n_frames_per_clip),
+                                      continuous=bool(self.cfg.stac.continuous))
+        eng.set_site_pos(torch.as_tensor(np.asarray(offsets, dtype=np.float32)).reshape(-1, 3))
+        n_clips = batched.shape[0]
+        lo, hi = dist.shard_range(n_clips)
+        kp = torch.as_tensor(batched[lo:hi]).to(eng.device)
+        if self._root_kp_idx == -1:
+            self._log("Missing or invalid ROOT_OPTIMIZATION_KEYPOINT, skipping root_optimization()")
+        res = self._q_phase(kp, do_root_opt=self.setup.do_root_opt)
+        if dist.is_dist():
+            res = {k: (dist.all_gather_clips(v, n_clips) if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
+        _, mean, std = self._get_error_stats(res["frame_error"].cpu().numpy())
+        self._log(f"Mean: {mean}\nStandard deviation: {std}")
+        self._offsets = eng.get_site_pos()
+        return self._package_data(res, batched, batched=True)
+
+    # -- packing (stac.py:456-503) ---------------------------------------------------------------------------
+    def _package_data(self, res, kp_data, batched=False) -> StacData:
+        """Clip-major flatten of every field.  (The reference flattens ``marker_sites`` frame-major when
+        C > 1 and F > 1 -- SURVEY.md A5-7, a reference bug; here all fields share the clip-major order.)"""
+        nq, nb, K = self.setup.tables.nq, self.setup.tables.nbody, self.setup.tables.nsite
+        qpos = res["qpos"].reshape(-1, nq).cpu().numpy()
+        xpos = res["xpos"].reshape(-1, nb, 3).cpu().numpy()
+        xquat = res["xquat"].reshape(-1, nb, 4).cpu().numpy()
+        markers = res["marker_sites"].reshape(-1, K, 3).cpu().numpy()
+        offsets = np.asarray(torch.as_tensor(self._offsets).cpu()).reshape(K, 3)
+        kp_flat = np.asarray(kp_data).reshape(-1, np.asarray(kp_data).shape[-1])
+        return StacData(qpos=qpos, xpos=xpos, xquat=xquat, marker_sites=markers, offsets=offsets,
+                        names_qpos=self._part_names, names_xpos=self._body_names, kp_data=kp_flat,
+                        kp_names=self._kp_names)

@@ -1,0 +1,128 @@
+"""The reference-shaped host API (Stac / StacCore / run_stac) on the GPU vs oracle-driven restatements."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(rodent_cfg, **stac_over):
+    from stac_mjx_amd.config import validate_config
+
+    stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=10,
+                skip_fit_offsets=False, skip_ik_only=False, infer_qvels=False, n_frames_per_clip=2,
+                mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+    stac.update(stac_over)
+    return validate_config({"model": dict(rodent_cfg), "stac": stac})
+
+
+def _oracle_fit_offsets(fs, cfgm, kp, n_iters):
+    """Test-side restatement of Stac.fit_offsets (stac.py:253-354) driven by the CPU oracle."""
+    from oracle import Oracle
+    from stac_mjx_amd.prng import sample_time_indices
+
+    orc = Oracle(fs.tables, tol=float(cfgm["FTOL"]), maxiter=int(cfgm["N_ITER_Q"]))
+    offsets = fs.tables.site_pos.copy()
+    q, _ = orc.root_optimization(kp, fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
+    idx = sample_time_indices(kp.shape[0], int(cfgm["N_SAMPLE_FRAMES"]))
+    for _ in range(n_iters):
+        out = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
+        q = out["carry_qpos"]
+        offsets, _ = orc.m_opt(kp[idx], out["qpos"][idx], offsets, fs.is_regularized, float(cfgm["M_REG_COEF"]))
+        orc.set_site_pos(offsets)
+    out = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
+    return offsets, out
+
+
+def test_fit_offsets_config1_bit_exact(rodent_setup, rodent_cfg, rodent_mocap):
+    """BASELINE config 1: real mocap, n_fit_frames=10, offset/pose alternation."""
+    from stac_mjx_amd.stac import Stac
+
+    cfg = _cfg(rodent_cfg)
+    cfg.model.N_ITERS = 2  # keeps the CPU oracle side short; the alternation logic is the same
+    kp = rodent_mocap[:10]
+    stac = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False)
+    data = stac.fit_offsets(kp)
+    ref_off, ref = _oracle_fit_offsets(rodent_setup, rodent_cfg, kp, 2)
+    np.testing.assert_array_equal(data.offsets, ref_off)
+    np.testing.assert_array_equal(data.qpos, ref["qpos"])
+    np.testing.assert_array_equal(data.marker_sites, ref["marker_sites"])
+    np.testing.assert_array_equal(data.xquat, ref["xquat"])
+    assert np.abs(data.offsets - ref_off).max() <= 1e-4 and np.abs(data.qpos - ref["qpos"]).max() <= 1e-4
+    assert data.qpos.shape == (10, 74) and data.xpos.shape == (10, 67, 3) and data.kp_data.shape == (10, 69)
+    assert data.names_qpos[0] == "root" and data.names_xpos[1] == "walker"
+    # offsets moved, and the fit improved over the initial offsets
+    assert np.abs(data.offsets - rodent_setup.tables.site_pos).max() > 1e-3
+    err = np.linalg.norm(data.marker_sites - kp.reshape(10, 23, 3), axis=-1).mean()
+    assert err < 6e-3
+
+
+def test_ik_only_clip_major_packing(rodent_setup, rodent_cfg, rodent_mocap):
+    from oracle import Oracle
+    from stac_mjx_amd.stac import Stac
+
+    cfg = _cfg(rodent_cfg, n_frames_per_clip=2)
+    kp = rodent_mocap[300:310]
+    off = rodent_setup.tables.site_pos + 0.002
+    stac = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False)
+    data = stac.ik_only(kp, off)
+    orc = Oracle(rodent_setup.tables, tol=1e-4, maxiter=400)
+    orc.set_site_pos(off)
+    fs = rodent_setup
+    ref = orc.ik_clips(kp.reshape(5, 2, 69), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    np.testing.assert_array_equal(data.qpos, ref["qpos"].reshape(10, 74))
+    np.testing.assert_array_equal(data.marker_sites, ref["marker_sites"].reshape(10, 23, 3))
+    np.testing.assert_array_equal(data.xpos, ref["xpos"].reshape(10, 67, 3))
+    np.testing.assert_array_equal(data.offsets, off)
+    np.testing.assert_array_equal(data.kp_data, kp)
+
+
+def test_seam_level_drivers_equal_batched_kernel(rodent_setup, rodent_cfg, rodent_mocap):
+    """compute_stac drivers over StacCore.q_opt (one launch per solve) == one stac_q_phase launch."""
+    from stac_mjx_amd import compute_stac, utils
+    from stac_mjx_amd.stac import Stac
+    from stac_mjx_amd.stac_core import DataHandle
+
+    cfg = _cfg(rodent_cfg)
+    fs = rodent_setup
+    stac = Stac(None, cfg, fs.kp_names, setup=fs, verbose=False)
+    kp = torch.as_tensor(rodent_mocap[50:52]).to(stac.engine.device)
+    model = stac._model_handle()
+    data = utils.kinematics(model, DataHandle(qpos=torch.as_tensor(fs.tables.qpos0).to(stac.engine.device)))
+    core = stac.stac_core_obj
+    data = compute_stac.root_optimization(core, model, data, kp, fs.root_kp_idx, fs.lb, fs.ub, None, fs.trunk_kps)
+    parts = [torch.as_tensor(m) for m in fs.part_masks]
+    data, qposes, xposes, xquats, markers, _, errs = compute_stac.pose_optimization(core, model, data, kp, fs.lb, fs.ub, None, parts)
+    res = stac.engine.q_phase(kp[None], part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                              root_dims=fs.root_dims, do_root_opt=True)
+    assert torch.equal(qposes, res["qpos"][0])
+    assert torch.equal(torch.stack(markers), res["marker_sites"][0])
+    assert torch.equal(torch.stack(xquats), res["xquat"][0])
+    np.testing.assert_array_equal(np.array(errs, np.float32), res["frame_error"][0].cpu().numpy())
+    # offset_optimization through the seam == engine.m_opt on the sampled frames
+    model2, data2, off = compute_stac.offset_optimization(core, model, data, kp, model.site_pos, qposes, 100,
+                                                          torch.as_tensor(fs.is_regularized), None, 1.0)
+    assert torch.equal(model2.site_pos, off) and off.shape == (23, 3)
+
+
+def test_run_stac_end_to_end(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
+    from stac_mjx_amd.io import load_stac_data
+    from stac_mjx_amd.main import run_stac
+
+    cfg = _cfg(rodent_cfg, n_fit_frames=4, n_frames_per_clip=2)
+    cfg.model.N_ITERS = 1
+    kp = rodent_mocap[:8]
+    fit_path, ik_path = run_stac(cfg, kp, rodent_setup.kp_names, base_path=tmp_path, setup=rodent_setup)
+    _, fit = load_stac_data(fit_path)
+    _, ik = load_stac_data(ik_path)
+    assert fit.qpos.shape == (4, 74) and ik.qpos.shape == (8, 74) and ik.xquat.shape == (8, 67, 4)
+    np.testing.assert_array_equal(ik.offsets, fit.offsets)
+    with pytest.raises(ValueError, match="n_frames_per_clip"):
+        cfg3 = _cfg(rodent_cfg, n_fit_frames=4, n_frames_per_clip=3, skip_fit_offsets=True)
+        run_stac(cfg3, kp, rodent_setup.kp_names, base_path=tmp_path, setup=rodent_setup)
+    cfg2 = _cfg(rodent_cfg, n_fit_frames=4, skip_ik_only=True)
+    cfg2.model.N_ITERS = 1
+    assert run_stac(cfg2, kp, rodent_setup.kp_names, base_path=tmp_path, setup=rodent_setup)[1] is None

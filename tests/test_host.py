@@ -1,0 +1,291 @@
+"""Host logic on CPU: config, io, batching, PRNG, seam protocol, C-ABI symbols (no GPU compute)."""
+
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import REFERENCE, ROOT
+
+
+# ---- C ABI -----------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from stac_mjx_amd.build import build_extension
+    from stac_mjx_amd.engine import ABI_SYMBOLS, load_library
+
+    build_extension()
+    header = (ROOT / "include" / "stac_hip.h").read_text()
+    declared = set(re.findall(r"\b(stac_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
+    lib = load_library()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.stac_abi_version() == 1
+    assert lib.stac_device_count() >= 0
+
+
+def test_engine_fails_loudly_without_gpu(rodent_setup):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from stac_mjx_amd.engine import Engine, StacHipError
+
+    with pytest.raises(StacHipError):
+        Engine(rodent_setup.tables, rodent_setup.lb, rodent_setup.ub)
+
+
+def test_product_never_imports_oracle():
+    for p in (ROOT / "stac_mjx_amd").rglob("*.py"):
+        txt = p.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt, p
+    for p in (ROOT / "stac_mjx_amd" / "csrc").iterdir():
+        if p.suffix in (".hip", ".hpp", ".cpp", ".h"):
+            assert '#include "../../oracle' not in p.read_text() and "stac_oracle.h" not in p.read_text(), p
+
+
+# ---- PRNG ------------------------------------------------------------------------------------------------
+def test_threefry_known_answer_vectors():
+    """Random123 / JAX test-suite KATs."""
+    from stac_mjx_amd.prng import threefry2x32
+
+    def one(key, ctr):
+        a, b = threefry2x32(key, np.array([ctr[0]], np.uint32), np.array([ctr[1]], np.uint32))
+        return int(a[0]), int(b[0])
+
+    assert one((0, 0), (0, 0)) == (0x6B200159, 0x99BA4EFE)
+    assert one((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF)) == (0x1CB996FC, 0xBB002BE7)
+    assert one((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3)) == (0xC4923A9C, 0x483DF7A0)
+
+
+def test_permutation_is_a_permutation_and_stable():
+    from stac_mjx_amd.prng import permutation, prng_key, sample_time_indices
+
+    p = permutation(prng_key(0), 1000)
+    assert sorted(p.tolist()) == list(range(1000))
+    assert p[:10].tolist() == [166, 872, 474, 336, 210, 769, 0, 475, 36, 835]  # value predicted in SURVEY.md A3
+    assert permutation(prng_key(0), 10).tolist() == [0, 1, 8, 5, 6, 4, 3, 2, 7, 9]
+    assert sorted(sample_time_indices(10, 100).tolist()) == list(range(10))  # n <= N_SAMPLE_FRAMES: all frames
+    assert len(sample_time_indices(5000, 100)) == 100
+
+
+# ---- config ------------------------------------------------------------------------------------------------
+def _write_cfg(tmp_path, rodent_cfg, n_fit_frames=42):
+    (tmp_path / "stac").mkdir()
+    (tmp_path / "model").mkdir()
+    (tmp_path / "config.yaml").write_text("defaults:\n  - stac: s1\n  - model: m1\n  - _self_\n")
+    stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False,
+                n_fit_frames=n_fit_frames, skip_fit_offsets=False, skip_ik_only=False, infer_qvels=False,
+                n_frames_per_clip=1, mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+    (tmp_path / "stac" / "s1.yaml").write_text(yaml.safe_dump(stac))
+    (tmp_path / "stac" / "s2.yaml").write_text(yaml.safe_dump({**stac, "n_fit_frames": 7}))
+    (tmp_path / "model" / "m1.yaml").write_text(yaml.safe_dump(rodent_cfg))
+    return tmp_path
+
+
+def test_compose_config_defaults_overrides_and_schema(tmp_path, rodent_cfg):
+    from stac_mjx_amd.config import ConfigError, compose_config, load_configs
+
+    d = _write_cfg(tmp_path, rodent_cfg)
+    cfg = load_configs(d)
+    assert cfg.stac.n_fit_frames == 42 and cfg.model.N_ITER_Q == 400 and cfg.model.FTOL == 1e-4
+    assert cfg.model.MARKER_SIZE == 0.005 and cfg.stac.mujoco.solver == "newton"
+    assert list(cfg.model.KEYPOINT_MODEL_PAIRS)[0] == "AnkleL"  # key order preserved
+    cfg2 = compose_config(d, overrides=["stac=s2", "stac.n_frames_per_clip=250", "model.FTOL=0.005",
+                                        "hydra/job_logging=disabled"])
+    assert cfg2.stac.n_fit_frames == 7 and cfg2.stac.n_frames_per_clip == 250 and cfg2.model.FTOL == 0.005
+    assert "ROOT_OPTIMIZATION_KEYPOINT" in cfg.model and cfg.model.get("NOPE", 3) == 3
+    with pytest.raises(ConfigError):
+        compose_config(d, overrides=["stac.bogus_key=1"])
+    with pytest.raises(ConfigError):
+        compose_config(d, config_name="missing")
+    rt = yaml.safe_load(cfg.to_yaml())
+    assert rt["model"]["SCALE_FACTOR"] == 0.9
+
+
+@pytest.mark.skipif(not REFERENCE.exists(), reason="reference checkout not present")
+def test_reference_config_dirs_load():
+    from stac_mjx_amd.config import compose_config
+
+    cfg = compose_config(REFERENCE / "configs", "config")
+    assert cfg.stac.n_fit_frames == 10 and cfg.model.MJCF_PATH == "models/rodent.xml"
+    cfgt = compose_config(REFERENCE / "tests" / "configs", "config")
+    assert cfgt.stac.n_fit_frames == 42 and cfgt.stac.n_frames_per_clip == 1  # tests/unit/test_config.py
+
+
+# ---- io -------------------------------------------------------------------------------------------------------
+def test_load_data_mat_ordering_and_scaling(tmp_path, rodent_cfg):
+    """Restates tests/test_io.py: sorted keypoint order == KEYPOINT_MODEL_PAIRS key order, shape (F, 3K)."""
+    import scipy.io as spio
+
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.io import load_data
+
+    names = rodent_cfg["KP_NAMES"]
+    rng = np.random.default_rng(0)
+    pred = rng.normal(0, 100, (12, 3, 23))
+    spio.savemat(tmp_path / "d.mat", {"pred": pred})
+    stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=4,
+                skip_fit_offsets=False, skip_ik_only=True, infer_qvels=False, n_frames_per_clip=1,
+                mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+    cfg = validate_config({"model": rodent_cfg, "stac": stac})
+    kp, sorted_names = load_data(cfg, base_path=tmp_path)
+    assert kp.shape == (12, 69) and kp.dtype == np.float32
+    assert sorted_names == list(rodent_cfg["KEYPOINT_MODEL_PAIRS"].keys())
+    k = sorted_names.index("SpineL")
+    np.testing.assert_allclose(kp[3, 3 * k: 3 * k + 3], pred[3, :, names.index("SpineL")] * 1e-3, rtol=1e-6)
+    cfg.model.KP_NAMES = names[:-1]
+    with pytest.raises(ValueError):
+        load_data(cfg, base_path=tmp_path)
+    cfg.stac.data_path = "d.txt"
+    with pytest.raises(ValueError):
+        load_data(cfg, base_path=tmp_path)
+
+
+def test_committed_mocap_fixture_matches_reference_mat(rodent_mocap):
+    if not REFERENCE.exists():
+        pytest.skip("reference checkout not present")
+    import scipy.io as spio
+
+    pred = spio.loadmat(REFERENCE / "tests/data/test_rodent_mocap_1000_frames.mat")["pred"]
+    assert rodent_mocap.shape == (1000, 69)
+    # column 0..2 = AnkleL = index 17 of KP_NAMES
+    np.testing.assert_allclose(rodent_mocap[5, :3], (pred[5, :, 17] * 1e-3).astype(np.float32))
+
+
+def test_save_and_load_stac_data_roundtrip(tmp_path, rodent_cfg):
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.io import StacData, load_stac_data, save_data_to_h5
+
+    stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=4,
+                skip_fit_offsets=False, skip_ik_only=True, infer_qvels=False, n_frames_per_clip=1,
+                mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+    cfg = validate_config({"model": rodent_cfg, "stac": stac})
+    d = StacData(qpos=np.ones((2, 74), np.float32), xpos=np.zeros((2, 67, 3), np.float32), xquat=np.zeros((2, 67, 4), np.float32),
+                 marker_sites=np.zeros((2, 23, 3), np.float32), offsets=np.full((23, 3), 0.5, np.float32),
+                 kp_data=np.zeros((2, 69), np.float32), names_qpos=["a"] * 74, names_xpos=["b"] * 67, kp_names=["c"] * 23)
+    p = save_data_to_h5(config=cfg, file_path=tmp_path / "fit.h5", **d.as_dict())
+    cfg2, d2 = load_stac_data(tmp_path / "fit.h5")
+    assert p.exists() and cfg2.stac.n_fit_frames == 4 and d2.names_qpos == ["a"] * 74
+    np.testing.assert_array_equal(d2.offsets, d.offsets)
+    np.testing.assert_array_equal(d2.qpos, d.qpos)
+
+
+# ---- batching (tests/unit/test_utils_math.py shapes) -----------------------------------------------------------------
+def test_batch_kp_data_shapes_and_content():
+    from stac_mjx_amd.utils import batch_kp_data, handle_edge_effects
+
+    kp = np.arange(8 * 6, dtype=np.float32).reshape(8, 6)
+    b = batch_kp_data(kp, 4)
+    assert b.shape == (2, 4, 6)
+    np.testing.assert_array_equal(b[1, 0], kp[4])
+    kp2 = np.arange(60 * 6, dtype=np.float32).reshape(60, 6)
+    c = batch_kp_data(kp2, 20, continuous=True)
+    assert c.shape == (3, 30, 6)
+    np.testing.assert_array_equal(c[0], kp2[:30])
+    np.testing.assert_array_equal(c[2, :20], kp2[40:60])
+    np.testing.assert_array_equal(c[2, 20:], kp2[40:50])  # wrap padding of the last window
+    assert batch_kp_data(kp2[:59], 20).shape == (2, 20, 6)  # trailing frames dropped
+    data = types.SimpleNamespace(qpos=c.copy(), kp_data=c.copy(), xpos=c.copy(), xquat=c.copy(), marker_sites=c.copy())
+    for k in vars(data):
+        setattr(data, k, getattr(data, k).reshape(-1, 6))
+    out = handle_edge_effects(data, 20)
+    assert out.qpos.shape == (60, 6)
+    np.testing.assert_allclose(out.qpos[:20], kp2[:20])
+
+
+# ---- seam protocol (tests/unit/test_compute_stac.py restated) ----------------------------------------------------------
+class FakeData:
+    def __init__(self, qpos, site_xpos=None, xpos=None, xquat=None):
+        self.qpos = qpos
+        self.site_xpos = site_xpos if site_xpos is not None else torch.zeros(2, 3)
+        self.xpos = xpos if xpos is not None else torch.zeros(2, 3)
+        self.xquat = xquat if xquat is not None else torch.zeros(2, 4)
+
+    def replace(self, **kw):
+        return FakeData(kw.get("qpos", self.qpos), kw.get("site_xpos", self.site_xpos), kw.get("xpos", self.xpos),
+                        kw.get("xquat", self.xquat))
+
+
+class FakeModel:
+    def __init__(self, nq, jnt_type, site_pos):
+        self.nq, self.jnt_type, self.site_pos = nq, jnt_type, site_pos
+
+
+class FakeStacCore:
+    def __init__(self):
+        self.q_calls = self.m_calls = 0
+        self.q0_args = []
+
+    def q_opt(self, *args, **kw):
+        self.q_calls += 1
+        self.q0_args.append(args[5])
+        return args[1], types.SimpleNamespace(params=args[5], state=types.SimpleNamespace(error=0.0))
+
+    def m_opt(self, mjx_model, mjx_data, keypoints, q, initial_offsets, *a, **kw):
+        self.m_calls += 1
+        return types.SimpleNamespace(params=torch.as_tensor(initial_offsets).reshape(-1, 3), error=0.0)
+
+
+@pytest.fixture()
+def patched_utils(monkeypatch):
+    from stac_mjx_amd import utils
+
+    monkeypatch.setattr(utils, "kinematics", lambda model, data: data)
+    monkeypatch.setattr(utils, "com_pos", lambda model, data: data)
+
+    def set_site_pos(model, offsets, site_idxs=None):
+        model.site_pos = offsets
+        return model
+
+    monkeypatch.setattr(utils, "set_site_pos", set_site_pos)
+    return utils
+
+
+def test_root_optimization_calls_q_opt_twice_and_seeds_root(patched_utils):
+    from stac_mjx_amd import compute_stac
+
+    core = FakeStacCore()
+    model = FakeModel(7, np.array([0]), torch.zeros(2, 3))
+    data = FakeData(torch.tensor([91.0, 92, 93, 4, 5, 6, 7]))
+    kp = torch.tensor([[11.0, 12, 13, 21, 22, 23]])
+    out = compute_stac.root_optimization(core, model, data, kp, 1, torch.zeros(7), torch.ones(7), torch.tensor([0, 1]),
+                                         torch.tensor([True, True]))
+    assert isinstance(out, FakeData) and core.q_calls == 2
+    exp = torch.tensor([21.0, 22, 23, 4, 5, 6, 7])
+    assert torch.allclose(core.q0_args[0], exp) and torch.allclose(core.q0_args[1], exp)
+
+
+def test_offset_optimization_updates_site_pos(patched_utils):
+    from stac_mjx_amd import compute_stac
+
+    core = FakeStacCore()
+    model = FakeModel(7, np.array([0]), torch.zeros(2, 3))
+    offsets = torch.zeros(2, 3)
+    model, data, off = compute_stac.offset_optimization(core, model, FakeData(torch.zeros(7)), torch.zeros(4, 6), offsets,
+                                                        torch.zeros(4, 7), 2, torch.zeros(2, 3), torch.tensor([0, 1]), 0.0)
+    assert core.m_calls == 1 and torch.allclose(off, offsets) and torch.allclose(model.site_pos, offsets)
+
+
+def test_pose_optimization_runs_all_frames(patched_utils):
+    from stac_mjx_amd import compute_stac
+
+    core = FakeStacCore()
+    model = FakeModel(7, np.array([0]), torch.zeros(2, 3))
+    res = compute_stac.pose_optimization(core, model, FakeData(torch.zeros(7)), torch.zeros(2, 6), torch.zeros(7),
+                                         torch.ones(7), torch.tensor([0, 1]), [])
+    _, qposes, _, _, marker_sites, _, frame_error = res
+    assert qposes.shape == (2, 7) and len(marker_sites) == 2 and len(frame_error) == 2 and core.q_calls == 2
+
+
+def test_run_stac_validates_columns_before_touching_the_gpu(tmp_path, rodent_cfg):
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.main import run_stac
+
+    stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=4,
+                skip_fit_offsets=False, skip_ik_only=True, infer_qvels=False, n_frames_per_clip=1,
+                mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+    cfg = validate_config({"model": rodent_cfg, "stac": stac})
+    with pytest.raises(ValueError, match="columns"):
+        run_stac(cfg, np.zeros((4, 68), np.float32), ["k"] * 23, base_path=tmp_path)
