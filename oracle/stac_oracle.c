@@ -25,37 +25,39 @@ typedef ORC_REAL real;
 #define R(x) ((real)(x))
 
 static inline real rsqrt_(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
+/* Fused multiply-add: one rounding, exactly what v_fma_f32 does on the GPU (build with -mfma so gcc
+ * emits the hardware instruction; glibc's fmaf is exact too, only slower). */
+static inline real FMA(real a, real b, real c) { return sizeof(real) == 4 ? (real)fmaf((float)a, (float)b, (float)c) : (real)fma((double)a, (double)b, (double)c); }
 
-/* sin/cos of the hinge half-angle.  The float32 build uses its own Cody-Waite + minimax
- * polynomial (cephes sinf/cosf coefficients) written with plain mul/add only, so that the HIP
- * kernels -- which contain the same operation sequence -- reproduce it bit for bit (libm's and
+/* sin/cos of the hinge half-angle.  The float32 build uses its own Cody-Waite reduction + minimax
+ * polynomial (cephes sinf/cosf coefficients) written as an explicit sequence of mul/fma, so that the
+ * HIP kernels -- which contain the same operation sequence -- reproduce it bit for bit (libm's and
  * OCML's sinf differ in the last ulp).  Max error ~1.5 ulp for |a| < 100. */
 static inline void sincos_(real a, real *sn, real *cs) {
     if (sizeof(real) != 4) { *sn = (real)sin((double)a); *cs = (real)cos((double)a); return; }
     const float x = (float)a;
     const float k = rintf(x * 0.636619772367581343f);            /* x * 2/pi, round-half-even */
-    float r = x - k * 1.5703125f;                                 /* pi/2 split in three */
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = fmaf(-k, 1.5703125f, x);                            /* pi/2 split in three */
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
     const float z = r * r;
-    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
-    ps = ps * z + -1.6666654611e-1f;
-    const float s0 = r + r * z * ps;
-    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    const float c0 = (1.0f - 0.5f * z) + z * z * pc;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float s0 = fmaf(r * z, ps, r);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    const float c0 = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
     const int q = ((int)k) & 3;
     const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
     *sn = (real)((q & 2) ? -ss : ss);
     *cs = (real)(((q + 1) & 2) ? -cc : cc);
 }
 
-/* ---- mujoco.mjx._src.math restated ------------------------------------- */
-static inline real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* ---- mujoco.mjx._src.math restated, with explicit fma ------------------------ */
+static inline real dot3(const real *a, const real *b) { return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0])); }
 static inline void cross3(const real *a, const real *b, real *r) {
-    r[0] = a[1] * b[2] - a[2] * b[1];
-    r[1] = a[2] * b[0] - a[0] * b[2];
-    r[2] = a[0] * b[1] - a[1] * b[0];
+    const real r0 = FMA(a[1], b[2], -(a[2] * b[1]));
+    const real r1 = FMA(a[2], b[0], -(a[0] * b[2]));
+    const real r2 = FMA(a[0], b[1], -(a[1] * b[0]));
+    r[0] = r0; r[1] = r1; r[2] = r2;
 }
 /* rotate(vec, quat): r = 2(u.v)u + (s^2 - u.u)v + 2 s (u x v) */
 static inline void rotate(const real *v, const real *q, real *r) {
@@ -64,22 +66,23 @@ static inline void rotate(const real *v, const real *q, real *r) {
     real c[3];
     const real uv = dot3(u, v), uu = dot3(u, u);
     cross3(u, v, c);
-    for (int i = 0; i < 3; ++i) {
-        real t = R(2) * (uv * u[i]) + (s * s - uu) * v[i];
-        r[i] = t + R(2) * s * c[i];
-    }
+    const real k = FMA(s, s, -uu), t = uv + uv, s2 = s + s;
+    const real r0 = FMA(s2, c[0], FMA(k, v[0], t * u[0]));
+    const real r1 = FMA(s2, c[1], FMA(k, v[1], t * u[1]));
+    const real r2 = FMA(s2, c[2], FMA(k, v[2], t * u[2]));
+    r[0] = r0; r[1] = r1; r[2] = r2;
 }
 static inline void qmul(const real *u, const real *v, real *r) {
     real t[4];
-    t[0] = u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3];
-    t[1] = u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2];
-    t[2] = u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1];
-    t[3] = u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0];
+    t[0] = FMA(-u[3], v[3], FMA(-u[2], v[2], FMA(-u[1], v[1], u[0] * v[0])));
+    t[1] = FMA(-u[3], v[2], FMA(u[2], v[3], FMA(u[1], v[0], u[0] * v[1])));
+    t[2] = FMA(u[3], v[1], FMA(u[2], v[0], FMA(-u[1], v[3], u[0] * v[2])));
+    t[3] = FMA(u[3], v[0], FMA(-u[2], v[1], FMA(u[1], v[2], u[0] * v[3])));
     r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
 }
 /* normalize(x) = x / (|x| + 1e-6 [|x| == 0]); returns |x| */
 static inline real normalize4(real *q) {
-    real n = rsqrt_(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    real n = rsqrt_(FMA(q[3], q[3], FMA(q[2], q[2], FMA(q[1], q[1], q[0] * q[0]))));
     real d = n + (n == R(0) ? R(1e-6) : R(0));
     for (int i = 0; i < 4; ++i) q[i] = q[i] / d;
     return n;
@@ -93,12 +96,29 @@ static inline void quat_to_mat(const real *q, real *m /* row-major 3x3 */) {
     m[6] = R(2) * (q13 - q02);    m[7] = R(2) * (q23 + q01);      m[8] = q00 - q11 - q22 + q33;
 }
 
+/* Pairwise (binary-tree) sum of n terms padded with zeros to a power of two: level h adds element
+ * i+h into element i for i = 0, 2h, 4h, ...  XLA's reduction order is unspecified; this is the order
+ * the HIP kernels use (lane butterflies, then registers) and it does not depend on how many lanes
+ * share a chain.  `buf` must hold next_pow2(n) elements; it is clobbered. */
+static real tree_sum(real *buf, int n) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = n; i < P; ++i) buf[i] = R(0);
+    for (int h = 1; h < P; h <<= 1)
+        for (int i = 0; i < P; i += 2 * h) buf[i] = buf[i] + buf[i + h];
+    return buf[0];
+}
+
 /* ---- workspace ------------------------------------------------------------------------- */
 typedef struct {
     real *mp;                               /* model tables converted to `real` */
     real *body_pos, *body_quat, *jnt_pos, *jnt_axis, *qpos0, *site_pos;
     real *qf, *xpos, *xquat, *xanchor, *xaxis, *jprequat, *jnorm, *sx, *F, *Tq;
     real *x, *y, *g, *cand, *xn, *gn, *tmp, *kp, *q0, *lb, *ub;
+    real *tb0, *tb1;  /* tree_sum scratch (power-of-two padded) */
+    real *sf, *st;    /* per-site force / moment */
+    int *sord;        /* site ids sorted by (body id, site id): subtrees are contiguous ranges */
+    int *blo, *bhi;   /* per body: range [lo, hi) of sorted-site positions inside its subtree */
     int ref_body; /* moments of the gradient wrenches are taken about xpos[ref_body] */
 } ws_t;
 
@@ -107,7 +127,11 @@ static ws_t *ws_new(const orc_model *m) {
     const int nb = m->nbody, nj = m->njnt, nq = m->nq, K = m->nsite;
     size_t n_model = (size_t)nb * 7 + (size_t)nj * 6 + nq + (size_t)K * 3;
     size_t n_fk = (size_t)nq + nb * 7 + nj * 6 + nj * 4 + nj + K * 3 + nb * 6;
-    size_t n_pg = (size_t)nq * 10 + K * 3;
+    int Pq = 1, Pk = 1;
+    while (Pq < nq) Pq <<= 1;
+    while (Pk < K) Pk <<= 1;
+    const int Pm = Pq > Pk ? Pq : Pk;
+    size_t n_pg = (size_t)nq * 10 + K * 3 + 2 * (size_t)Pm + 6 * (size_t)K;
     real *p = (real *)calloc(n_model + n_fk + n_pg + 64, sizeof(real));
     w->mp = p;
     w->body_pos = p; p += nb * 3;
@@ -136,6 +160,28 @@ static ws_t *ws_new(const orc_model *m) {
     w->xn = p; p += nq; w->gn = p; p += nq; w->tmp = p; p += nq; w->q0 = p; p += nq;
     w->lb = p; p += nq; w->ub = p; p += nq;
     w->kp = p; p += K * 3;
+    w->tb0 = p; p += Pm; w->tb1 = p; p += Pm;
+    w->sf = p; p += 3 * K; w->st = p; p += 3 * K;
+    /* sites sorted by (body, id); bodies are in DFS pre-order, so the sites of a subtree are contiguous */
+    {
+        w->sord = (int *)calloc((size_t)K + 2 * (size_t)nb + 2, sizeof(int));
+        w->blo = w->sord + K; w->bhi = w->blo + nb;
+        int *send = (int *)calloc(nb, sizeof(int)); /* last body id of each subtree */
+        for (int b = 0; b < nb; ++b) send[b] = b;
+        for (int b = nb - 1; b >= 1; --b) { const int pa = m->body_parentid[b]; if (send[b] > send[pa]) send[pa] = send[b]; }
+        int n = 0;
+        for (int b = 0; b < nb; ++b)
+            for (int k = 0; k < K; ++k)
+                if (m->site_bodyid[k] == b) w->sord[n++] = k;
+        for (int b = 0; b < nb; ++b) {
+            int lo = 0, hi = 0;
+            while (lo < K && m->site_bodyid[w->sord[lo]] < b) ++lo;
+            hi = lo;
+            while (hi < K && m->site_bodyid[w->sord[hi]] <= send[b]) ++hi;
+            w->blo[b] = lo; w->bhi[b] = hi;
+        }
+        free(send);
+    }
     /* ref_body = first body, ordered by (depth, id), that is an ancestor-or-self of a fit site
      * (the root body for every model of the reference). */
     {
@@ -153,7 +199,7 @@ static ws_t *ws_new(const orc_model *m) {
     return w;
 }
 static void ws_free(ws_t *w) {
-    if (w) { free(w->mp); free(w); }
+    if (w) { free(w->mp); free(w->sord); free(w); }
 }
 
 /* ---- forward kinematics (mjx smooth.kinematics) ---------------------------- */
@@ -209,7 +255,7 @@ static void fk_ws(const orc_model *m, ws_t *w, real *qpos) {
                 for (int i = 0; i < 3; ++i) anchor[i] = r[i] + pos[i];
                 rotate(jax, quat, axis);
                 const real d = qpos[a] - w->qpos0[a];
-                for (int i = 0; i < 3; ++i) pos[i] += axis[i] * d;
+                for (int i = 0; i < 3; ++i) pos[i] = FMA(axis[i], d, pos[i]);
             } break;
             default: break;
             }
@@ -243,7 +289,7 @@ void orc_fk(const orc_model *m, float *qpos, float *xpos, float *xquat, float *x
 static real q_loss_ws(const orc_model *m, ws_t *w, const real *q, const real *kp,
                       const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const real *initial_q,
                       real *grad) {
-    const int nq = m->nq, K = m->nsite, nb = m->nbody;
+    const int nq = m->nq, K = m->nsite;
     /* make_qs (utils.py:129-144): (1 - mask) * q0 + mask * q */
     for (int i = 0; i < nq; ++i) {
         const real mi = qs_to_opt[i] ? R(1) : R(0);
@@ -251,42 +297,39 @@ static real q_loss_ws(const orc_model *m, ws_t *w, const real *q, const real *kp
     }
     fk_ws(m, w, w->qf);
     /* residual = (kp - markers) * kps_to_opt; loss = sum(residual^2)  (stac_core.py:57-61) */
-    /* summation order: per site (rx^2 + ry^2) + rz^2, then sites in index order (XLA's reduce
-     * order is unspecified; this is the order the HIP kernels reproduce exactly). */
-    real loss = R(0);
+    /* summation order: per site fma(rz,rz, fma(ry,ry, rx*rx)), then the pairwise tree over the sites. */
     for (int k = 0; k < K; ++k) {
         real r[3];
         for (int i = 0; i < 3; ++i) {
             const real wi = kps_to_opt[3 * k + i] ? R(1) : R(0);
             r[i] = (kp[3 * k + i] - w->sx[3 * k + i]) * wi;
         }
-        loss += (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        w->tb0[k] = FMA(r[2], r[2], FMA(r[1], r[1], r[0] * r[0]));
     }
+    const real loss = tree_sum(w->tb0, K);
     if (!grad) return loss;
 
-    /* dL/dx_k = -2 w (kp - x_k).  Subtree wrench sums about c = xpos[ref_body] (root body). */
+    /* dL/dx_k = -2 w (kp - x_k); moment of each site force about c = xpos[ref_body] (root body). */
     const real *c = w->xpos + 3 * w->ref_body;
-    memset(w->F, 0, sizeof(real) * nb * 3);
-    memset(w->Tq, 0, sizeof(real) * nb * 3);
     for (int k = 0; k < K; ++k) {
-        const int b = m->site_bodyid[k];
-        real f[3], d[3], t[3];
+        real f[3], d[3];
         for (int i = 0; i < 3; ++i) {
             const real wi = kps_to_opt[3 * k + i] ? R(1) : R(0);
             f[i] = R(-2) * ((kp[3 * k + i] - w->sx[3 * k + i]) * wi);
             d[i] = w->sx[3 * k + i] - c[i];
         }
-        cross3(d, f, t);
-        for (int i = 0; i < 3; ++i) { w->F[3 * b + i] += f[i]; w->Tq[3 * b + i] += t[i]; }
-    }
-    for (int b = nb - 1; b >= 1; --b) { /* children have larger ids than parents (DFS order) */
-        const int p = m->body_parentid[b];
-        for (int i = 0; i < 3; ++i) { w->F[3 * p + i] += w->F[3 * b + i]; w->Tq[3 * p + i] += w->Tq[3 * b + i]; }
+        cross3(d, f, w->st + 3 * k);
+        for (int i = 0; i < 3; ++i) w->sf[3 * k + i] = f[i];
     }
     for (int i = 0; i < nq; ++i) grad[i] = R(0);
     for (int j = 0; j < m->njnt; ++j) {
         const int b = m->jnt_bodyid[j], a = m->jnt_qposadr[j];
-        const real *F = w->F + 3 * b, *T0 = w->Tq + 3 * b;
+        /* subtree wrench of the joint's body: its sites in (body id, site id) order, from zero */
+        real F[3] = {R(0), R(0), R(0)}, T0[3] = {R(0), R(0), R(0)};
+        for (int i = w->blo[b]; i < w->bhi[b]; ++i) {
+            const int k = w->sord[i];
+            for (int c3 = 0; c3 < 3; ++c3) { F[c3] += w->sf[3 * k + c3]; T0[c3] += w->st[3 * k + c3]; }
+        }
         const real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
         real d[3], t[3], tau[3];
         for (int i = 0; i < 3; ++i) d[i] = anchor[i] - c[i];
@@ -314,7 +357,7 @@ static real q_loss_ws(const orc_model *m, ws_t *w, const real *q, const real *kp
             const real n = w->jnorm[j];
             const real dn = n + (n == R(0) ? R(1e-6) : R(0));
             grad[qa] = (R(-2) * dot3(tl, qh + 1)) / dn;
-            for (int i = 0; i < 3; ++i) grad[qa + 1 + i] = (R(2) * (qh[0] * tl[i] - uxt[i])) / dn;
+            for (int i = 0; i < 3; ++i) grad[qa + 1 + i] = (R(2) * FMA(qh[0], tl[i], -uxt[i])) / dn;
         } break;
         default: break;
         }
@@ -369,23 +412,23 @@ static void q_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const 
             ++grad_evals;
             /* backtracking line search from the current stepsize */
             real eta = stepsize;
-            for (int i = 0; i < nq; ++i) cand[i] = clipr(y[i] - eta * g[i], lb[i], ub[i]);
+            for (int i = 0; i < nq; ++i) cand[i] = clipr(FMA(-eta, g[i], y[i]), lb[i], ub[i]);
             int n = 0;
             for (;;) {
                 if (n >= p->maxls) break;
                 const real fc = q_loss_ws(m, w, cand, w->kp, qs_to_opt, kps_to_opt, w->q0, NULL);
                 ++ls_evals;
-                real sq = R(0), vd = R(0);
                 for (int i = 0; i < nq; ++i) {
                     const real d = cand[i] - y[i];
-                    sq += d * d;
-                    vd += d * g[i];
+                    w->tb0[i] = d * d;
+                    w->tb1[i] = d * g[i];
                 }
+                const real sq = tree_sum(w->tb0, nq), vd = tree_sum(w->tb1, nq);
                 const real lhs = eta * (fc - fy);
                 const real rhs = eta * vd + R(0.5) * sq + eps;
                 if (!(lhs > rhs)) break;
                 eta = eta * R(0.5);
-                for (int i = 0; i < nq; ++i) cand[i] = clipr(y[i] - eta * g[i], lb[i], ub[i]);
+                for (int i = 0; i < nq; ++i) cand[i] = clipr(FMA(-eta, g[i], y[i]), lb[i], ub[i]);
                 ++n;
             }
             const real next_step = (eta <= R(1e-6)) ? R(1) : eta / R(0.5);
@@ -393,18 +436,17 @@ static void q_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const 
             const real beta = (t - R(1)) / tn;
             for (int i = 0; i < nq; ++i) {
                 const real d = cand[i] - x[i];
-                y[i] = cand[i] + beta * d;
+                y[i] = FMA(beta, d, cand[i]);
                 x[i] = cand[i];
             }
             /* error = || clip(x_next - grad(x_next)) - x_next ||_2 */
             (void)q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, gn);
             ++grad_evals;
-            real e2 = R(0);
             for (int i = 0; i < nq; ++i) {
                 const real d = clipr(x[i] - gn[i], lb[i], ub[i]) - x[i];
-                e2 += d * d;
+                w->tb0[i] = d * d;
             }
-            error = rsqrt_(e2);
+            error = rsqrt_(tree_sum(w->tb0, nq));
             stepsize = next_step;
             t = tn;
             ++iter;

@@ -25,7 +25,8 @@
  * jaxopt/jax/mujoco cannot be imported here, so for the q_phase this oracle is
  * "PARITY UNPINNED": it is an algorithm restatement, not a verified replay of the reference.
  *
- * All arithmetic is IEEE float32, compiled with -ffp-contract=off.
+ * All arithmetic is IEEE float32 with explicit fmaf() in the kinematics (the operation sequence the HIP
+ * kernels execute), compiled with -ffp-contract=off so nothing else is contracted.
  */
 #ifndef STAC_ORACLE_H
 #define STAC_ORACLE_H

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,7 +16,7 @@
 #include "stac_plan.hpp"
 
 namespace stac {
-hipError_t launch_q_phase(const QArgs &a, int G, size_t lds_bytes, hipStream_t s, int *capacity_out);
+hipError_t launch_q_phase(const QArgs &a, int G, int wpb, size_t lds_bytes, hipStream_t s, int *capacity_out);
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s);
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
@@ -48,6 +49,7 @@ struct stac_model {
     int32_t *d_jnt_type = nullptr, *d_jnt_qposadr = nullptr;
     float *d_jnt_pos = nullptr, *d_jnt_axis = nullptr, *d_qpos0 = nullptr;
     int32_t *d_site_bodyid = nullptr;
+    float *d_site_pos = nullptr;  // [K,3] offsets for the stand-alone FK / m-phase kernels (mirrors the plan's SiteRec.pos)
     uint8_t *d_masks = nullptr;  // [kMaxKinds, nqpad] + [K] + [3K]
     size_t masks_bytes = 0;
     float *d_scratch = nullptr;  // grown on demand (xpos/xquat when the caller does not want them)
@@ -61,7 +63,7 @@ struct stac_model {
         M.jnt_type = d_jnt_type; M.jnt_qposadr = d_jnt_qposadr;
         M.jnt_pos = d_jnt_pos; M.jnt_axis = d_jnt_axis; M.qpos0 = d_qpos0;
         M.site_bodyid = d_site_bodyid;
-        M.site_pos = d_blob + h.off_site_pos;
+        M.site_pos = d_site_pos;
         return M;
     }
 };
@@ -144,20 +146,23 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         }
     }
     const int naj = (int)aj_type.size();
-    // own sites (ascending id) and children (descending body id)
-    std::vector<int> ab_sadr(nab), ab_snum(nab), site_list, ab_cadr(nab), ab_cnum(nab), child_list, ab_parent(nab);
+    // sites sorted by (body id, site id); per joint the range of sorted positions inside its body's subtree
+    std::vector<int> ab_parent(nab), sortpos(K), aj_slo(naj), aj_shi(naj), sorted;
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < K; ++k)
+            if (t->site_bodyid[k] == b) { sortpos[k] = (int)sorted.size(); sorted.push_back(k); }
+    std::vector<int> sub_end(nb);
+    for (int b = 0; b < nb; ++b) sub_end[b] = b;
+    for (int b = nb - 1; b >= 1; --b) sub_end[t->body_parentid[b]] = std::max(sub_end[t->body_parentid[b]], sub_end[b]);
     for (int s = 0; s < nab; ++s) {
         const int b = slots[s];
-        ab_sadr[s] = (int)site_list.size();
-        for (int k = 0; k < K; ++k)
-            if (t->site_bodyid[k] == b) site_list.push_back(k);
-        ab_snum[s] = (int)site_list.size() - ab_sadr[s];
-        ab_cadr[s] = (int)child_list.size();
-        for (int c = nb - 1; c >= 1; --c)
-            if (active[c] && t->body_parentid[c] == b) child_list.push_back(slot_of[c]);
-        ab_cnum[s] = (int)child_list.size() - ab_cadr[s];
         const int p = t->body_parentid[b];
         ab_parent[s] = p == 0 ? 0 : slot_of[p] + 1;
+        int lo = 0;
+        while (lo < K && t->site_bodyid[sorted[lo]] < b) ++lo;
+        int hi = lo;
+        while (hi < K && t->site_bodyid[sorted[hi]] <= sub_end[b]) ++hi;
+        for (int j = ab_jadr[s]; j < ab_jadr[s] + ab_jnum[s]; ++j) { aj_slo[j] = lo; aj_shi[j] = hi; }
     }
     // quaternion addresses of the whole model
     std::vector<int> quat_adr;
@@ -172,52 +177,56 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.nqpad = (nq + 3) & ~3;
     h.has_ball = has_ball;
     m->max_depth = nlev;
+    if (nab >= 65535 || K >= 65535) return fail(STAC_ERR_CAPACITY, "too many bodies / sites");
 
     std::vector<float> &B = m->blob_host;
     B.clear();
-    auto put_i = [&](const std::vector<int> &v, size_t pad_to = 0) {
+    auto align4 = [&]() { while (B.size() & 3) B.push_back(0.f); };
+    auto put_raw = [&](const void *src, size_t words) {
+        align4();
         int off = (int)B.size();
-        for (int x : v) { float f; std::memcpy(&f, &x, 4); B.push_back(f); }
-        while (B.size() < off + pad_to) B.push_back(0.f);
+        B.resize(B.size() + words);
+        std::memcpy(B.data() + off, src, words * 4);
+        align4();
         return off;
     };
-    auto put_f = [&](const std::vector<float> &v, size_t pad_to = 0) {
-        int off = (int)B.size();
-        for (float x : v) B.push_back(x);
-        while (B.size() < off + pad_to) B.push_back(0.f);
-        return off;
+    auto put_fpad = [&](const float *src, int n, int padded) {
+        std::vector<float> v(src, src + n);
+        v.resize(padded, 0.f);
+        return put_raw(v.data(), v.size());
     };
-    std::vector<float> ab_pos, ab_quat;
+    std::vector<BodyRec> brec(nab);
     for (int s = 0; s < nab; ++s) {
-        for (int i = 0; i < 3; ++i) ab_pos.push_back(t->body_pos[3 * slots[s] + i]);
-        for (int i = 0; i < 4; ++i) ab_quat.push_back(t->body_quat[4 * slots[s] + i]);
+        const int b = slots[s];
+        BodyRec &r = brec[s];
+        r.parent = ab_parent[s]; r.jadr = ab_jadr[s]; r.jnum = ab_jnum[s];
+        const float *q = t->body_quat + 4 * b;
+        r.flags = (q[0] == 1.0f && q[1] == 0.0f && q[2] == 0.0f && q[3] == 0.0f) ? 1 : 0;
+        for (int i = 0; i < 3; ++i) r.pos[i] = t->body_pos[3 * b + i];
+        r.pad = 0.f;
+        for (int i = 0; i < 4; ++i) r.quat[i] = q[i];
     }
-    std::vector<int> site_slot(K);
-    for (int k = 0; k < K; ++k) site_slot[k] = slot_of[t->site_bodyid[k]];
-    h.off_lev_adr = put_i(lev_adr);
-    h.off_ab_parent = put_i(ab_parent);
-    h.off_ab_jadr = put_i(ab_jadr);
-    h.off_ab_jnum = put_i(ab_jnum);
-    h.off_ab_sadr = put_i(ab_sadr);
-    h.off_ab_snum = put_i(ab_snum);
-    h.off_ab_cadr = put_i(ab_cadr);
-    h.off_ab_cnum = put_i(ab_cnum);
-    h.off_site_list = put_i(site_list);
-    h.off_child_list = put_i(child_list, 1);
-    h.off_ab_pos = put_f(ab_pos);
-    h.off_ab_quat = put_f(ab_quat);
-    h.off_aj_type = put_i(aj_type, 1);
-    h.off_aj_qadr = put_i(aj_qadr, 1);
-    h.off_aj_slot = put_i(aj_slot, 1);
-    h.off_aj_pos = put_f(aj_pos, 1);
-    h.off_aj_axis = put_f(aj_axis, 1);
-    h.off_aj_q0 = put_f(aj_q0, 1);
-    h.off_site_slot = put_i(site_slot);
-    h.off_site_pos = put_f(std::vector<float>(t->site_pos, t->site_pos + 3 * K));
-    h.off_lb = put_f(std::vector<float>(t->lb, t->lb + nq), h.nqpad);
-    h.off_ub = put_f(std::vector<float>(t->ub, t->ub + nq), h.nqpad);
-    h.off_qpos0 = put_f(std::vector<float>(t->qpos0, t->qpos0 + nq), h.nqpad);
-    h.off_quat_adr = put_i(quat_adr, 1);
+    std::vector<JointRec> jrec(std::max(naj, 1));
+    for (int j = 0; j < naj; ++j) {
+        JointRec &r = jrec[j];
+        r.type = aj_type[j]; r.qadr = aj_qadr[j]; r.slo = aj_slo[j]; r.shi = aj_shi[j];
+        for (int i = 0; i < 3; ++i) { r.pos[i] = aj_pos[3 * j + i]; r.axis[i] = aj_axis[3 * j + i]; }
+        r.q0 = aj_q0[j]; r.slot = aj_slot[j];
+    }
+    std::vector<SiteRec> srec(K);
+    for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < 3; ++i) srec[k].pos[i] = t->site_pos[3 * k + i];
+        srec[k].slot_sortpos = slot_of[t->site_bodyid[k]] | (sortpos[k] << 16);
+    }
+    h.off_lev_adr = put_raw(lev_adr.data(), lev_adr.size());
+    h.off_body = put_raw(brec.data(), brec.size() * sizeof(BodyRec) / 4);
+    h.off_joint = put_raw(jrec.data(), jrec.size() * sizeof(JointRec) / 4);
+    h.off_site = put_raw(srec.data(), srec.size() * sizeof(SiteRec) / 4);
+    h.off_lb = put_fpad(t->lb, nq, h.nqpad);
+    h.off_ub = put_fpad(t->ub, nq, h.nqpad);
+    h.off_qpos0 = put_fpad(t->qpos0, nq, h.nqpad);
+    quat_adr.push_back(0);
+    h.off_quat_adr = put_raw(quat_adr.data(), quat_adr.size());
     h.total_words = (int)B.size();
 
     // per-chain LDS layout
@@ -226,8 +235,10 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.c_ja = o; o += naj * 6;
     h.c_jq = o; o += has_ball ? naj * 4 : 0;
     h.c_jn = o; o += naj;
-    h.c_sw = o; o += std::max(K * 6, h.nqpad);
-    h.c_bw = o; o += std::max(std::max(nab * 6, 2 * h.nqpad), K);
+    o = (o + 3) & ~3;
+    h.c_sw = o; o += K * 6;
+    o = (o + 3) & ~3;
+    h.c_gg = o; o += std::max(h.nqpad, (K + 3) & ~3);
     o = (o + 3) & ~3;
     h.c_qe = o; o += h.nqpad;
     h.c_kp = o; o += 3 * K;
@@ -238,9 +249,35 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
 }
 
 static int q_mb_words(int nkinds, int G) { return (nkinds * G + 3) & ~3; }
-static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds) {
+static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
     const int plan_words = (h.total_words + 3) & ~3;
-    return (size_t)(plan_words + q_mb_words(nkinds, G) + (64 / G) * h.chain_stride) * sizeof(float);
+    return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * h.chain_stride) * sizeof(float);
+}
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr int kCus = 256;
+
+// Wavefronts per workgroup: the waves of a block share one copy of the plan, so more chains fit the
+// 160 KiB of a CU.  Returns the wpb (1..8) that maximises resident chains per CU for this G.
+static int pick_wpb(const PlanHeader &h, int G, int nkinds, int *waves_per_cu_out) {
+    // LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not fit a CU),
+    // and the kernel's register footprint (> 168 VGPRs) admits 2 waves per SIMD = 8 waves per CU.
+    constexpr size_t kGranule = 1280;
+#ifndef STAC_WAVES_BY_REGS
+#define STAC_WAVES_BY_REGS 8
+#endif
+    constexpr int kWavesByRegs = STAC_WAVES_BY_REGS;
+    int best = 0, best_waves = 0;
+    for (int wpb = 1; wpb <= 8; ++wpb) {
+        size_t lds = q_lds_bytes(h, G, nkinds, wpb);
+        if (lds > kLdsPerCu) break;
+        lds = (lds + kGranule - 1) / kGranule * kGranule;
+        int blocks = (int)(kLdsPerCu / lds);
+        if (blocks * wpb > kWavesByRegs) blocks = kWavesByRegs / wpb;  // whole workgroups only
+        const int waves = blocks * wpb;
+        if (waves > best_waves) { best_waves = waves; best = wpb; }  // ties: the smaller workgroup
+    }
+    if (waves_per_cu_out) *waves_per_cu_out = best_waves;
+    return best;
 }
 
 extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
@@ -266,6 +303,7 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     chk(upload(&m->d_jnt_axis, t->jnt_axis, (size_t)nj * 3));
     chk(upload(&m->d_qpos0, t->qpos0, (size_t)nq));
     chk(upload(&m->d_site_bodyid, t->site_bodyid, (size_t)K));
+    chk(upload(&m->d_site_pos, t->site_pos, (size_t)K * 3));
     m->masks_bytes = (size_t)kMaxKinds * m->h.nqpad + 4 * (size_t)K + 64;
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_masks), m->masks_bytes));
     if (e != hipSuccess) {
@@ -281,7 +319,7 @@ extern "C" void stac_model_destroy(stac_model *m) {
     if (!m) return;
     void *ptrs[] = {m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
                     m->d_body_quat, m->d_jnt_type, m->d_jnt_qposadr, m->d_jnt_pos, m->d_jnt_axis,
-                    m->d_qpos0, m->d_site_bodyid, m->d_masks, m->d_scratch};
+                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -300,15 +338,17 @@ extern "C" int32_t stac_model_info(const stac_model *m, int32_t *info) {
 
 extern "C" int32_t stac_set_site_pos(stac_model *m, const float *offsets, void *stream) {
     if (!m || !offsets) return fail(STAC_ERR_INVALID, "null argument");
-    HIP_TRY(hipMemcpyAsync(m->d_blob + m->h.off_site_pos, offsets, sizeof(float) * 3 * m->h.K,
-                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(m->d_site_pos, offsets, sizeof(float) * 3 * m->h.K, hipMemcpyDeviceToDevice, s));
+    // scatter into the plan's SiteRec.pos (stride 4 words)
+    HIP_TRY(hipMemcpy2DAsync(m->d_blob + m->h.off_site, sizeof(SiteRec), offsets, 3 * sizeof(float), 3 * sizeof(float),
+                             m->h.K, hipMemcpyDeviceToDevice, s));
     return STAC_OK;
 }
 
 extern "C" int32_t stac_get_site_pos(const stac_model *m, float *out, void *stream) {
     if (!m || !out) return fail(STAC_ERR_INVALID, "null argument");
-    HIP_TRY(hipMemcpyAsync(out, m->d_blob + m->h.off_site_pos, sizeof(float) * 3 * m->h.K,
-                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(out, m->d_site_pos, sizeof(float) * 3 * m->h.K, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return STAC_OK;
 }
 
@@ -333,14 +373,18 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
     return fk_impl(m, qpos, N, qn, xpos, xquat, site_xpos, 1, stream);
 }
 
-static int pick_lanes(const stac_model *m, int requested, int nchains) {
+// Lanes per chain.  Fewer lanes = more chains per wave instruction (throughput); more lanes = fewer
+// idle chains when there are few of them (latency).  Prefer the smallest G whose resident capacity
+// (chains that fit the chip at once) still covers all chains in ONE round with >= 2 waves per SIMD.
+static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
-    (void)m;
-    // Heuristic: more lanes per chain when there are few chains (latency), fewer when there are many
-    // (throughput).  256 CUs x 4 SIMDs; aim at >= 2 wavefronts per SIMD.
-    if (nchains >= 16384) return 8;
-    if (nchains >= 4096) return 16;
-    if (nchains >= 1024) return 32;
+    const int cand[] = {16, 32, 64};
+    for (int G : cand) {
+        int waves_cu = 0;
+        if (!pick_wpb(m->h, G, nkinds, &waves_cu)) continue;
+        const long capacity = (long)waves_cu * kCus * (64 / G);
+        if (nchains > capacity / 2) return G;  // enough chains to fill at least half the slots of this G
+    }
     return 64;
 }
 
@@ -353,24 +397,45 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     a.h = m->h;
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const int nkinds = a.single ? 1 : a.P + 3;
-    int G = pick_lanes(m, p->lanes_per_chain, nchains);
-    size_t lds = q_lds_bytes(m->h, G, nkinds);
-    while (lds > 160 * 1024 && G < 64) { G *= 2; lds = q_lds_bytes(m->h, G, nkinds); }
-    if (lds > 160 * 1024) return fail(STAC_ERR_CAPACITY, "model does not fit the 160 KiB LDS of a CU");
+    if (const char *f = getenv("STAC_HIP_FLAGS")) a.flags = atoi(f);  // developer A/B switches (see stac_plan.hpp)
+#ifdef STAC_PROFILE
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) { (void)hipMalloc(reinterpret_cast<void **>(&d_prof), 16 * sizeof(unsigned long long)); }
+    (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), s);
+    a.prof = d_prof;
+#endif
+    int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds);
+    hipError_t e = hipErrorInvalidValue;
     int cap = 0;
-    a.mb_words = q_mb_words(nkinds, G);
-    hipError_t e = launch_q_phase(a, G, lds, s, &cap);
-    if (e != hipSuccess && cap == 0) {
-        // no instantiation with this many lanes holds nq: widen the group
-        for (int g2 = G * 2; g2 <= 64 && cap == 0; g2 *= 2) {
-            lds = q_lds_bytes(m->h, g2, nkinds);
-            if (lds > 160 * 1024) continue;
-            a.mb_words = q_mb_words(nkinds, g2);
-            e = launch_q_phase(a, g2, lds, s, &cap);
+    for (; G <= 64; G *= 2) {
+        int wpb = pick_wpb(m->h, G, nkinds, nullptr);
+        if (!wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
+        if (const char *w = getenv("STAC_HIP_WPB")) {  // developer override
+            const int ww = atoi(w);
+            if (ww >= 1 && ww <= 8 && q_lds_bytes(m->h, G, nkinds, ww) <= kLdsPerCu) wpb = ww;
         }
-        if (cap == 0) return fail(STAC_ERR_CAPACITY, "nq exceeds the compiled q_phase kernel capacity (256)");
+        if (getenv("STAC_HIP_VERBOSE"))
+            fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
+                    nchains, G, wpb, q_lds_bytes(m->h, G, nkinds, wpb), m->h.chain_stride, m->h.total_words);
+        a.mb_words = q_mb_words(nkinds, G);
+        e = launch_q_phase(a, G, wpb, q_lds_bytes(m->h, G, nkinds, wpb), s, &cap);
+        if (cap) break;  // an instantiation with this many lanes holds nq
     }
+    if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");
     if (e != hipSuccess) return fail(STAC_ERR_HIP, std::string("q_phase launch: ") + hipGetErrorString(e));
+#ifdef STAC_PROFILE
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost);
+        static const char *names[] = {"loop", "stage", "fk", "sites", "loss_sum", "wrench", "joint_grad", "trans_sums", "accept_fused", "end_solve", "-", "-"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += h[i];
+        fprintf(stderr, "[stac profile] G=%d", G);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        fprintf(stderr, " total_wave_cycles=%.3g\n", (double)tot);
+    }
+#endif
     return STAC_OK;
 }
 

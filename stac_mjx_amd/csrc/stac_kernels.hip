@@ -34,9 +34,10 @@ namespace stac {
 struct V3 { float x, y, z; };
 struct Q4 { float w, x, y, z; };
 
-__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return FMA(a.z, b.z, FMA(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ V3 cross3(V3 a, V3 b) {
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return {FMA(a.y, b.z, -(a.z * b.y)), FMA(a.z, b.x, -(a.x * b.z)), FMA(a.x, b.y, -(a.y * b.x))};
 }
 __device__ __forceinline__ V3 add3(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -47,41 +48,36 @@ __device__ __forceinline__ V3 rotate(V3 v, Q4 q) {
     const V3 u = {q.x, q.y, q.z};
     const float uv = dot3(u, v), uu = dot3(u, u);
     const V3 c = cross3(u, v);
-    const float k = s * s - uu, s2 = 2.0f * s;
-    V3 r;
-    r.x = (2.0f * (uv * u.x) + k * v.x) + s2 * c.x;
-    r.y = (2.0f * (uv * u.y) + k * v.y) + s2 * c.y;
-    r.z = (2.0f * (uv * u.z) + k * v.z) + s2 * c.z;
-    return r;
+    const float k = FMA(s, s, -uu), t = uv + uv, s2 = s + s;
+    return {FMA(s2, c.x, FMA(k, v.x, t * u.x)), FMA(s2, c.y, FMA(k, v.y, t * u.y)), FMA(s2, c.z, FMA(k, v.z, t * u.z))};
 }
 __device__ __forceinline__ Q4 qmul(Q4 u, Q4 v) {
     Q4 r;
-    r.w = u.w * v.w - u.x * v.x - u.y * v.y - u.z * v.z;
-    r.x = u.w * v.x + u.x * v.w + u.y * v.z - u.z * v.y;
-    r.y = u.w * v.y - u.x * v.z + u.y * v.w + u.z * v.x;
-    r.z = u.w * v.z + u.x * v.y - u.y * v.x + u.z * v.w;
+    r.w = FMA(-u.z, v.z, FMA(-u.y, v.y, FMA(-u.x, v.x, u.w * v.w)));
+    r.x = FMA(-u.z, v.y, FMA(u.y, v.z, FMA(u.x, v.w, u.w * v.x)));
+    r.y = FMA(u.z, v.x, FMA(u.y, v.w, FMA(-u.x, v.z, u.w * v.y)));
+    r.z = FMA(u.z, v.w, FMA(-u.y, v.x, FMA(u.x, v.y, u.w * v.z)));
     return r;
 }
 // normalize(x) = x / (|x| + 1e-6 [|x| == 0]); returns |x| through *n
 __device__ __forceinline__ Q4 normalize4(Q4 q, float *n_out) {
-    const float n = __builtin_sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const float n = __builtin_sqrtf(FMA(q.z, q.z, FMA(q.y, q.y, FMA(q.x, q.x, q.w * q.w))));
     const float d = n + (n == 0.0f ? 1e-6f : 0.0f);
     *n_out = n;
     return {q.w / d, q.x / d, q.y / d, q.z / d};
 }
-// Cody-Waite + cephes minimax sin/cos, plain mul/add: the oracle's sincos_ operation for operation.
+// Cody-Waite + cephes minimax sin/cos as an explicit mul/fma sequence: the oracle's sincos_ operation
+// for operation.
 __device__ __forceinline__ void sincos_(float x, float *sn, float *cs) {
     const float k = __builtin_rintf(x * 0.636619772367581343f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = FMA(-k, 1.5703125f, x);
+    r = FMA(-k, 4.837512969970703125e-4f, r);
+    r = FMA(-k, 7.54978995489188216e-8f, r);
     const float z = r * r;
-    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
-    ps = ps * z + -1.6666654611e-1f;
-    const float s0 = r + r * z * ps;
-    float pc = 2.443315711809948e-5f * z + -1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    const float c0 = (1.0f - 0.5f * z) + z * z * pc;
+    const float ps = FMA(FMA(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float s0 = FMA(r * z, ps, r);
+    const float pc = FMA(FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    const float c0 = FMA(z * z, pc, FMA(-0.5f, z, 1.0f));
     const int q = ((int)k) & 3;
     const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
     *sn = (q & 2) ? -ss : ss;
@@ -94,33 +90,106 @@ __device__ __forceinline__ Q4 ld4(const float *p) { return {p[0], p[1], p[2], p[
 __device__ __forceinline__ void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 __device__ __forceinline__ void st4(float *p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 
+// ---- cross-lane sums (oracle: tree_sum) ---------------------------------------------------------------
+// The value held by the lane whose index differs in bit H.  Levels are applied in increasing H, so when
+// H >= 4 every lane of the 4- (8-, 16-) lane block already holds the same partial sum and a mirrored
+// read from the neighbouring block returns exactly the xor-partner's value: all of it stays on DPP.
+template <int H>
+__device__ __forceinline__ float xor_partner(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    if constexpr (H == 1) r = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (H == 2) r = __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (H == 4) r = __builtin_amdgcn_update_dpp(i, i, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (H == 8) r = __builtin_amdgcn_update_dpp(i, i, 0x140, 0xF, 0xF, true);  // row_mirror
+    else if constexpr (H == 16) r = __builtin_amdgcn_ds_swizzle(i, 0x401F);                   // xor 16 inside 32 lanes
+    else r = __shfl_xor(i, 32, 64);
+    return __builtin_bit_cast(float, r);
+}
+// Pairwise-tree sum over the elements e = r*G + lane_in_group of a striped vector (zeros beyond nq):
+// lane butterflies for the levels below G, then the registers.  Every lane of the group gets the sum.
+template <int G, int NQR>
+__device__ __forceinline__ float group_tree_sum(const float (&v)[NQR]) {
+    constexpr int PR = NQR <= 1 ? 1 : NQR <= 2 ? 2 : NQR <= 4 ? 4 : NQR <= 8 ? 8 : NQR <= 16 ? 16 : 32;
+    float t[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        float x = r < NQR ? v[r] : 0.0f;
+        if constexpr (G >= 2) x = x + xor_partner<1>(x);
+        if constexpr (G >= 4) x = x + xor_partner<2>(x);
+        if constexpr (G >= 8) x = x + xor_partner<4>(x);
+        if constexpr (G >= 16) x = x + xor_partner<8>(x);
+        if constexpr (G >= 32) x = x + xor_partner<16>(x);
+        if constexpr (G >= 64) x = x + xor_partner<32>(x);
+        t[r] = x;
+    }
+#pragma unroll
+    for (int h = 1; h < PR; h *= 2)
+#pragma unroll
+        for (int i = 0; i < PR; i += 2 * h) t[i] = t[i] + t[i + h];
+    return t[0];
+}
+
 enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3 };
+
+// In-kernel phase stamps: diagnostic build only (-DSTAC_PROFILE -> libstac_hip_prof.so); the stamps
+// go to a buffer of their own and feed no output.  Read the SHARES, not the run time.
+#ifdef STAC_PROFILE
+#define PROF_DECL unsigned long long pt0 = __builtin_readcyclecounter(), pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_TICK(i)                                             \
+    do {                                                         \
+        const unsigned long long pt1 = __builtin_readcyclecounter(); \
+        pacc[i] += pt1 - pt0;                                    \
+        pt0 = pt1;                                               \
+    } while (0)
+#define PROF_FLUSH(a)                                                                     \
+    do {                                                                                  \
+        if (a.prof && lane == 0)                                                          \
+            for (int i = 0; i < 12; ++i) atomicAdd(a.prof + i, pacc[i]);                  \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF_TICK(i)
+#define PROF_FLUSH(a)
+#endif
 enum : int { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
 
-// One wavefront per workgroup: a barrier only has to order this wave's LDS traffic.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// Chains never span wavefronts, so ordering this wave's own LDS traffic is enough: LDS operations of
+// one wave execute in issue order; the fence stops the compiler from moving or caching LDS accesses
+// across the point (it lowers to s_waitcnt lgkmcnt(0)), the wave barrier pins the schedule.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ------------------------------------------------------------------------------------------------
 // q_phase kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef STAC_WAVES_PER_EU
+#define STAC_WAVES_PER_EU 2
+#endif
+
+__device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast<const int4 *>(p); }
+
 template <int G, int NQR>
-__global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STAC_WAVES_PER_EU, STAC_WAVES_PER_EU)))
+void q_phase_kernel(const QArgs a) {
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
     const PlanHeader &H = a.h;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int grp = lane / G, lg = lane % G;
     const int nq = H.nq, K = H.K, nqpad = H.nqpad;
 
-    // ---- stage the plan into LDS -------------------------------------------------------------
+    // ---- stage the plan into LDS (shared by the block's wavefronts) ------------------------------------
     float *P = lds;
-    const int *PI = reinterpret_cast<const int *>(lds);
-    for (int i = lane; i < H.total_words; i += 64) P[i] = a.plan[i];
+    for (int i = threadIdx.x; i < H.total_words; i += blockDim.x) P[i] = a.plan[i];
     const int plan_words = (H.total_words + 3) & ~3;
     // per-kind qs_to_opt bit masks, one 32-bit word per (kind, lane-in-group): bit r <-> element r*G+lg
     uint32_t *MB = reinterpret_cast<uint32_t *>(lds + plan_words);
     const int nkinds = a.single ? 1 : a.P + 3;
-    for (int i = lane; i < nkinds * G; i += 64) {
+    for (int i = threadIdx.x; i < nkinds * G; i += blockDim.x) {
         const int kind = i / G, l = i % G;
         uint32_t bits = 0;
         for (int r = 0; r < NQR; ++r) {
@@ -129,27 +198,19 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
         }
         MB[i] = bits;
     }
-    float *CB = lds + plan_words + a.mb_words + grp * H.chain_stride;  // this chain's region
+    float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jq = CB + H.c_jq, *jn = CB + H.c_jn;
-    float *sw = CB + H.c_sw, *gg = CB + H.c_sw, *bw = CB + H.c_bw, *r2 = CB + H.c_bw, *red = CB + H.c_bw;
+    float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
     float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
-    wave_sync();
+    __syncthreads();  // the only workgroup-wide barrier: the plan is shared by the block's waves
 
-    const int *lev_adr = PI + H.off_lev_adr, *ab_parent = PI + H.off_ab_parent;
-    const int *ab_jadr = PI + H.off_ab_jadr, *ab_jnum = PI + H.off_ab_jnum;
-    const int *ab_sadr = PI + H.off_ab_sadr, *ab_snum = PI + H.off_ab_snum;
-    const int *ab_cadr = PI + H.off_ab_cadr, *ab_cnum = PI + H.off_ab_cnum;
-    const int *site_list = PI + H.off_site_list, *child_list = PI + H.off_child_list;
-    const float *ab_pos = P + H.off_ab_pos, *ab_quat = P + H.off_ab_quat;
-    const int *aj_type = PI + H.off_aj_type, *aj_qadr = PI + H.off_aj_qadr, *aj_slot = PI + H.off_aj_slot;
-    const float *aj_pos = P + H.off_aj_pos, *aj_axis = P + H.off_aj_axis, *aj_q0 = P + H.off_aj_q0;
-    const int *site_slot = PI + H.off_site_slot;
-    const float *site_pos = P + H.off_site_pos;
+    const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
+    const float *brec = P + H.off_body, *jrec = P + H.off_joint, *srec = P + H.off_site;
     const float *lbv = P + H.off_lb, *ubv = P + H.off_ub, *qpos0 = P + H.off_qpos0;
-    const int *quat_adr = PI + H.off_quat_adr;
+    const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
     // ---- per-chain solver state (uniform inside a group) ------------------------------------------
-    const int chain = blockIdx.x * CPW + grp;
+    const int chain = (blockIdx.x * wpb + wave) * CPW + grp;
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
     int frame = 0, iter = 0, nls = 0;
@@ -187,11 +248,18 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
     for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; cand[r] = q0[r]; }
     wave_sync();
 
+    PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
     while (__any(st != ST_DONE)) {
+        PROF_TICK(0);  // loop control
         const int st_in = st;
         const uint32_t mbits = MB[kind * G + lg];
-        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X);
+        // A line-search candidate that is accepted becomes x_next, whose gradient the stopping test
+        // needs (the oracle's separate VG_X evaluation runs the very same FK).  The step size doubles
+        // after every iteration, so the first candidate is almost always rejected and the second
+        // accepted: evaluate the gradient together with every candidate after the first.
+        const bool ls_with_grad = (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
+        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_with_grad;
         const bool any_grad = __any(want_grad);
 
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
@@ -205,22 +273,43 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
             }
         }
         wave_sync();
+        PROF_TICK(1);  // stage
 
         // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
         for (int lev = 0; lev < H.nlev; ++lev) {
             const int s_end = lev_adr[lev + 1];
             for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
-                const float *pp = bx + ab_parent[s] * 7;
+                const float *br = brec + 12 * s;
+                const int4 bi = lds4i(br);       // parent, jadr, jnum, flags
+                const float4 bp = lds4(br + 4);  // pos
+                const float *pp = bx + bi.x * 7;
                 const V3 ppos = ld3(pp);
                 const Q4 pquat = ld4(pp + 3);
-                V3 pos = add3(ppos, rotate(ld3(ab_pos + 3 * s), pquat));
-                Q4 quat = qmul(pquat, ld4(ab_quat + 4 * s));
-                const int j0 = ab_jadr[s], j1 = j0 + ab_jnum[s];
-                for (int j = j0; j < j1; ++j) {
-                    const int ty = aj_type[j], ad = aj_qadr[j];
-                    const V3 jp = ld3(aj_pos + 3 * j), jax = ld3(aj_axis + 3 * j);
+                V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
+                Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
+                if (!(bi.w & 1)) {
+                    const float4 bq = lds4(br + 8);
+                    quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
+                }
+                const int j1 = bi.y + bi.z;
+                for (int j = bi.y; j < j1; ++j) {
+                    const float *jr = jrec + 12 * j;
+                    const int4 ji = lds4i(jr);        // type, qadr, slo, shi
+                    const float4 jp4 = lds4(jr + 4);  // pos, q0
+                    const float4 ja4 = lds4(jr + 8);  // axis, slot
+                    const int ty = ji.x, ad = ji.y;
+                    const V3 jp = {jp4.x, jp4.y, jp4.z}, jax = {ja4.x, ja4.y, ja4.z};
                     V3 anchor, axis;
-                    if (ty == JFREE) {
+                    if (ty == JHINGE) {
+                        anchor = add3(rotate(jp, quat), pos);
+                        axis = rotate(jax, quat);
+                        const float angle = qe[ad] - jp4.w;
+                        float sn, cs;
+                        sincos_(angle * 0.5f, &sn, &cs);
+                        const Q4 qloc = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
+                        quat = qmul(quat, qloc);
+                        pos = sub3(anchor, rotate(jp, quat));
+                    } else if (ty == JFREE) {
                         anchor = ld3(qe + ad);
                         pos = anchor;
                         axis = {0.f, 0.f, 1.f};
@@ -228,20 +317,11 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
                         quat = normalize4(ld4(qe + ad + 3), &n);
                         st4(qe + ad + 3, quat);  // written back, like MJX
                         jn[j] = n;
-                    } else if (ty == JHINGE) {
-                        anchor = add3(rotate(jp, quat), pos);
-                        axis = rotate(jax, quat);
-                        const float angle = qe[ad] - aj_q0[j];
-                        float sn, cs;
-                        sincos_(angle * 0.5f, &sn, &cs);
-                        const Q4 qloc = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
-                        quat = qmul(quat, qloc);
-                        pos = sub3(anchor, rotate(jp, quat));
                     } else if (ty == JSLIDE) {
                         anchor = add3(rotate(jp, quat), pos);
                         axis = rotate(jax, quat);
-                        const float d = qe[ad] - aj_q0[j];
-                        pos = {pos.x + axis.x * d, pos.y + axis.y * d, pos.z + axis.z * d};
+                        const float d = qe[ad] - jp4.w;
+                        pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
                     } else {  // ball
                         anchor = add3(rotate(jp, quat), pos);
                         axis = rotate(jax, quat);
@@ -262,12 +342,17 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
             wave_sync();
         }
 
+        PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
         const V3 cref = ld3(bx + 7);  // slot 0 = first active body (the root): moments are taken about it
         const bool trunk_w = (!a.single) && kind < 2;
+        const int Kpad = (K + 3) & ~3;
+        for (int k = K + lg; k < Kpad; k += G) r2[k] = 0.0f;  // zero padding of the loss tree
         for (int k = lg; k < K; k += G) {
-            const float *bp = bx + (site_slot[k] + 1) * 7;
-            const V3 sx = add3(ld3(bp), rotate(ld3(site_pos + 3 * k), ld4(bp + 3)));
+            const float4 sr = lds4(srec + 4 * k);
+            const int ss = __builtin_bit_cast(int, sr.w);
+            const float *bp = bx + ((ss & 0xFFFF) + 1) * 7;
+            const V3 sx = add3(ld3(bp), rotate(V3{sr.x, sr.y, sr.z}, ld4(bp + 3)));
             float w0, w1, w2;
             if (a.single) {
                 w0 = a.kpw3[3 * k] ? 1.f : 0.f; w1 = a.kpw3[3 * k + 1] ? 1.f : 0.f; w2 = a.kpw3[3 * k + 2] ? 1.f : 0.f;
@@ -275,54 +360,73 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
                 w0 = w1 = w2 = (trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f);
             }
             const float rx = (kpl[3 * k] - sx.x) * w0, ry = (kpl[3 * k + 1] - sx.y) * w1, rz = (kpl[3 * k + 2] - sx.z) * w2;
-            const float term = (rx * rx + ry * ry) + rz * rz;
+            const float term = FMA(rz, rz, FMA(ry, ry, rx * rx));
             if (any_grad) {
                 const V3 f = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
                 const V3 tq = cross3(sub3(sx, cref), f);
-                st3(sw + 6 * k, f);
-                st3(sw + 6 * k + 3, tq);
+                const int sp = ss >> 16;
+                st3(sw + 6 * sp, f);
+                st3(sw + 6 * sp + 3, tq);
             }
             r2[k] = term;
         }
         wave_sync();
-        float loss = 0.0f;
-        for (int k = 0; k < K; ++k) loss += r2[k];  // every lane: same order, broadcast LDS reads
+        PROF_TICK(3);  // sites
+        // pairwise tree over the sites (oracle: tree_sum), every lane redundantly from broadcast LDS reads:
+        // r2 is padded with zeros to a multiple of 4; levels 1 and 2 inside each float4, then across them.
+        float loss;
+        {
+            const int n4 = Kpad >> 2;
+            if (n4 <= 8) {
+                float acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i] = 0.0f;
+                    if (i < n4) {
+                        const float4 q4 = lds4(r2 + 4 * i);
+                        acc[i] = (q4.x + q4.y) + (q4.z + q4.w);
+                    }
+                }
+                // adding the zero padding is exact, so the tree over 8 float4 equals the oracle's tree
+                loss = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            } else {
+                float acc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    acc[i] = 0.0f;
+                    if (i < n4) {
+                        const float4 q4 = lds4(r2 + 4 * i);
+                        acc[i] = (q4.x + q4.y) + (q4.z + q4.w);
+                    }
+                }
+#pragma unroll
+                for (int h = 1; h < 16; h *= 2)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2 * h) acc[i] = acc[i] + acc[i + h];
+                loss = acc[0];
+            }
+        }
         wave_sync();
-
+        PROF_TICK(4);  // loss sum
         float gnew[NQR];
 #pragma unroll
         for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
         if (any_grad) {
-            // ---- subtree wrench sums, leaves to root (oracle: sites in id order, then children in
-            //      decreasing id order) --------------------------------------------------------------
-            for (int lev = H.nlev - 1; lev >= 0; --lev) {
-                const int s_end = lev_adr[lev + 1];
-                for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
-                    V3 Fs = {0.f, 0.f, 0.f}, Ts = {0.f, 0.f, 0.f};
-                    const int k0 = ab_sadr[s], k1 = k0 + ab_snum[s];
-                    for (int i = k0; i < k1; ++i) {
-                        const int k = site_list[i];
-                        Fs = add3(Fs, ld3(sw + 6 * k));
-                        Ts = add3(Ts, ld3(sw + 6 * k + 3));
-                    }
-                    const int c0 = ab_cadr[s], c1 = c0 + ab_cnum[s];
-                    for (int i = c0; i < c1; ++i) {
-                        const int c = child_list[i];
-                        Fs = add3(Fs, ld3(bw + 6 * c));
-                        Ts = add3(Ts, ld3(bw + 6 * c + 3));
-                    }
-                    st3(bw + 6 * s, Fs);
-                    st3(bw + 6 * s + 3, Ts);
-                }
-                wave_sync();
-            }
-            // gg aliases sw: all site wrenches have been consumed
+            // r2 (aliased by gg) has been consumed by the loss sum
             for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
             wave_sync();
-            // ---- per-joint gradient ---------------------------------------------------
+            PROF_TICK(5);  // zero gg
+            // ---- per-joint gradient: subtree wrench of the joint's body = its sites in
+            //      (body id, site id) order, summed from zero, then the joint formulas ---------------------
             for (int j = lg; j < H.naj; j += G) {
-                const int ty = aj_type[j], ad = aj_qadr[j], s = aj_slot[j];
-                const V3 Fs = ld3(bw + 6 * s), T0 = ld3(bw + 6 * s + 3);
+                const float *jr = jrec + 12 * j;
+                const int4 ji = lds4i(jr);  // type, qadr, slo, shi
+                const int ty = ji.x, ad = ji.y;
+                V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
+                for (int i = ji.z; i < ji.w; ++i) {
+                    Fs = add3(Fs, ld3(sw + 6 * i));
+                    T0 = add3(T0, ld3(sw + 6 * i + 3));
+                }
                 const V3 anchor = ld3(ja + 6 * j), axis = ld3(ja + 6 * j + 3);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
                 if (ty == JHINGE) {
@@ -345,9 +449,9 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
                     const float n = jn[j];
                     const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
                     gg[qa] = (-2.0f * dot3(tl, u)) / dn;
-                    gg[qa + 1] = (2.0f * (qh.w * tl.x - uxt.x)) / dn;
-                    gg[qa + 2] = (2.0f * (qh.w * tl.y - uxt.y)) / dn;
-                    gg[qa + 3] = (2.0f * (qh.w * tl.z - uxt.z)) / dn;
+                    gg[qa + 1] = (2.0f * FMA(qh.w, tl.x, -uxt.x)) / dn;
+                    gg[qa + 2] = (2.0f * FMA(qh.w, tl.y, -uxt.y)) / dn;
+                    gg[qa + 3] = (2.0f * FMA(qh.w, tl.z, -uxt.z)) / dn;
                 }
             }
             wave_sync();
@@ -357,6 +461,7 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
                 if (e < nq && ((mbits >> r) & 1u)) gnew[r] = gg[e];
             }
             wave_sync();
+            PROF_TICK(6);  // joint gradients
         }
 
         // ---- solver transitions (jaxopt ProjectedGradient) ------------------------------------
@@ -368,54 +473,54 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
                 g[r] = gnew[r];
-                if (e < nq) cand[r] = clipf(y[r] - eta * g[r], lbv[e], ubv[e]);
+                if (e < nq) cand[r] = clipf(FMA(-eta, g[r], y[r]), lbv[e], ubv[e]);
             }
             c_grad++; s_grad++;
             st = ST_LS;
-        } else if (st_in == ST_LS) {
+        }
+        // nq-sums as pairwise trees over the striped registers (oracle: tree_sum); all groups compute
+        // them every trip (a few dozen DPP adds), only the groups in the matching state use them
+        float sum0, sum1;
+        {
+            float t0[NQR], t1[NQR];
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
+                float a0 = 0.0f, a1 = 0.0f;
                 if (e < nq) {
-                    const float d = cand[r] - y[r];
-                    red[e] = d * d;
-                    red[nqpad + e] = d * g[r];
+                    if (st_in == ST_VG_X) {
+                        const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
+                        a0 = d * d;
+                    } else {
+                        const float d = cand[r] - y[r];
+                        a0 = d * d;
+                        a1 = d * g[r];
+                    }
                 }
+                t0[r] = a0;
+                t1[r] = a1;
             }
-        } else if (st_in == ST_VG_X) {
-#pragma unroll
-            for (int r = 0; r < NQR; ++r) {
-                const int e = r * G + lg;
-                if (e < nq) {
-                    const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
-                    red[e] = d * d;
-                }
-            }
+            sum0 = group_tree_sum<G, NQR>(t0);
+            sum1 = group_tree_sum<G, NQR>(t1);
         }
-        wave_sync();
-        float sum0 = 0.0f, sum1 = 0.0f;
-        if (st_in == ST_LS) {
-            for (int e = 0; e < nq; ++e) { sum0 += red[e]; sum1 += red[nqpad + e]; }
-        } else if (st_in == ST_VG_X) {
-            for (int e = 0; e < nq; ++e) sum0 += red[e];
-        }
-        wave_sync();
-
+        PROF_TICK(7);  // transition terms + nq sums
         bool ending = false;
+        bool fused = false;  // accepted a candidate whose gradient is already in gnew
         if (st_in == ST_LS) {
             c_ls++; s_ls++;
             const float lhs = eta * (loss - fy);
             const float rhs = eta * sum1 + 0.5f * sum0 + eps;
             bool accept = !(lhs > rhs);
+            const bool evaluated_point_accepted = accept;
             if (!accept) {
                 eta = eta * 0.5f;
                 nls++;
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
-                    if (e < nq) cand[r] = clipf(y[r] - eta * g[r], lbv[e], ubv[e]);
+                    if (e < nq) cand[r] = clipf(FMA(-eta, g[r], y[r]), lbv[e], ubv[e]);
                 }
-                if (nls >= a.maxls) accept = true;
+                if (nls >= a.maxls) accept = true;  // taken without evaluation, like jaxopt's loop bound
             }
             if (accept) {
                 next_step = (eta <= 1e-6f) ? 1.0f : eta / 0.5f;
@@ -424,12 +529,31 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const float d = cand[r] - x[r];
-                    y[r] = cand[r] + beta * d;
+                    y[r] = FMA(beta, d, cand[r]);
                     x[r] = cand[r];
                 }
                 st = ST_VG_X;
+                fused = ls_with_grad && evaluated_point_accepted;
             }
-        } else if (st_in == ST_VG_X) {
+        }
+        // stopping residual of x_next: either this trip evaluated x (VG_X) or the accepted candidate
+        // came with its gradient (fused)
+        if (__any(fused)) {
+            float t0[NQR];
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                float a0 = 0.0f;
+                if (e < nq) {
+                    const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
+                    a0 = d * d;
+                }
+                t0[r] = a0;
+            }
+            const float e2 = group_tree_sum<G, NQR>(t0);
+            if (fused) sum0 = e2;
+        }
+        if (st_in == ST_VG_X || fused) {
             fx = loss;
             error = __builtin_sqrtf(sum0);
             stepsize = next_step;
@@ -440,6 +564,7 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
             else ending = true;
         }
 
+        PROF_TICK(8);  // accept / fused residual
         // ---- end of a solve: replace_qs (utils.py:147-169), next solve / next frame ------------------------
         if (__any(ending)) {
             if (ending) {
@@ -526,7 +651,9 @@ __global__ __launch_bounds__(64) void q_phase_kernel(const QArgs a) {
             }
             wave_sync();
         }
+        PROF_TICK(9);  // end of solve
     }
+    PROF_FLUSH(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +695,7 @@ __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, 
             } else if (ty == JSLIDE) {
                 const V3 axis = rotate(jax, quat);
                 const float d = q[ad] - M.qpos0[ad];
-                pos = {pos.x + axis.x * d, pos.y + axis.y * d, pos.z + axis.z * d};
+                pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
             } else {
                 const V3 anchor = add3(rotate(jp, quat), pos);
                 float nn;
@@ -658,24 +785,25 @@ __global__ void m_finish_kernel(int K, const float *partial, const float *m0, co
 // launchers (called from stac_abi.hip)
 // ------------------------------------------------------------------------------------------------
 template <int G, int NQR>
-static hipError_t launch_q(const QArgs &a, size_t lds_bytes, hipStream_t s) {
+static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = 64 / G;
-    const int blocks = (a.C + CPW - 1) / CPW;
+    const int per_block = CPW * wpb;
+    const int blocks = (a.C + per_block - 1) / per_block;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((q_phase_kernel<G, NQR>), dim3(blocks), dim3(64), lds_bytes, s, a);
+    hipLaunchKernelGGL((q_phase_kernel<G, NQR>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-// nq capacity of an instantiation is G*NQR.
-hipError_t launch_q_phase(const QArgs &a, int G, size_t lds_bytes, hipStream_t s, int *capacity_out) {
+// nq capacity of an instantiation is G*NQR.  wpb = wavefronts per workgroup (they share the plan copy).
+hipError_t launch_q_phase(const QArgs &a, int G, int wpb, size_t lds_bytes, hipStream_t s, int *capacity_out) {
     const int nq = a.h.nq;
     *capacity_out = 0;
 #define STAC_TRY(GG, RR)                                   \
     if (G == GG && nq <= GG * RR) {                        \
         *capacity_out = GG * RR;                           \
-        return launch_q<GG, RR>(a, lds_bytes, s);          \
+        return launch_q<GG, RR>(a, wpb, lds_bytes, s);     \
     }
     STAC_TRY(4, 20) STAC_TRY(4, 32)
     STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)

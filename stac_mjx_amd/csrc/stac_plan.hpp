@@ -11,6 +11,31 @@ namespace stac {
 
 constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 
+// Records are 16-byte aligned so the kernel fetches them with ds_read_b128.
+struct BodyRec {      // 12 words
+    int32_t parent;   // index into the per-chain transform array: 0 = world, s+1 = slot s
+    int32_t jadr;     // first joint record
+    int32_t jnum;
+    int32_t flags;    // bit 0: body_quat is the identity (product with it is exact, skipped)
+    float pos[3];
+    float pad;
+    float quat[4];
+};
+struct JointRec {     // 12 words
+    int32_t type;     // mjtJoint
+    int32_t qadr;
+    int32_t slo;      // sorted-site range [slo, shi) of the joint's body subtree
+    int32_t shi;
+    float pos[3];
+    float q0;         // qpos0[qadr] (hinge / slide reference)
+    float axis[3];
+    int32_t slot;     // body slot
+};
+struct SiteRec {      // 4 words
+    float pos[3];     // the marker offset -- mutable (stac_set_site_pos writes the blob)
+    int32_t slot_sortpos;  // body slot | sorted position << 16
+};
+
 struct PlanHeader {
     int32_t nbody, njnt, nq, K;
     int32_t nab;     // active bodies (ancestors-or-self of a fit site), sorted by (depth, id)
@@ -19,39 +44,23 @@ struct PlanHeader {
     int32_t nquat;   // quaternion joints (free / ball) in the WHOLE model
     int32_t nqpad;   // nq rounded up to a multiple of 4
     int32_t has_ball;
-    // word offsets into the blob -------------------------------------------------------------
-    int32_t off_lev_adr;     // [nlev+1] first slot of each level
-    int32_t off_ab_parent;   // [nab] parent's index in the per-chain transform array (0 = world, s+1 = slot s)
-    int32_t off_ab_jadr;     // [nab] first active joint
-    int32_t off_ab_jnum;     // [nab]
-    int32_t off_ab_sadr;     // [nab] own sites: start in site_list
-    int32_t off_ab_snum;     // [nab]
-    int32_t off_ab_cadr;     // [nab] children: start in child_list
-    int32_t off_ab_cnum;     // [nab]
-    int32_t off_site_list;   // [K]  site ids grouped by body slot, increasing id inside a body
-    int32_t off_child_list;  // [nab] child slots, DEcreasing body id inside a parent (oracle order)
-    int32_t off_ab_pos;      // [nab*3] float
-    int32_t off_ab_quat;     // [nab*4] float
-    int32_t off_aj_type;     // [naj]
-    int32_t off_aj_qadr;     // [naj]
-    int32_t off_aj_slot;     // [naj] body slot
-    int32_t off_aj_pos;      // [naj*3] float
-    int32_t off_aj_axis;     // [naj*3] float
-    int32_t off_aj_q0;       // [naj] float: qpos0[qadr] (hinge / slide reference)
-    int32_t off_site_slot;   // [K]
-    int32_t off_site_pos;    // [K*3] float -- the marker offsets; mutable (stac_set_site_pos)
-    int32_t off_lb;          // [nqpad] float
-    int32_t off_ub;          // [nqpad] float
-    int32_t off_qpos0;       // [nqpad] float
-    int32_t off_quat_adr;    // [nquat] qpos address of every quaternion (free: adr+3, ball: adr)
+    // word offsets into the blob (all multiples of 4) ---------------------------------------------
+    int32_t off_lev_adr;   // [nlev+1] first slot of each level
+    int32_t off_body;      // BodyRec[nab]
+    int32_t off_joint;     // JointRec[naj]
+    int32_t off_site;      // SiteRec[K]
+    int32_t off_lb;        // [nqpad] float
+    int32_t off_ub;        // [nqpad] float
+    int32_t off_qpos0;     // [nqpad] float
+    int32_t off_quat_adr;  // [nquat] qpos address of every quaternion (free: adr+3, ball: adr)
     int32_t total_words;
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
     int32_t c_bx;      // [(nab+1)*7] pos(3) quat(4); entry 0 = world
     int32_t c_ja;      // [naj*6] anchor(3) axis(3)
     int32_t c_jq;      // [naj*4] quaternion before a ball joint (only if has_ball)
-    int32_t c_jn;      // [naj]   |q| of free/ball quaternions
-    int32_t c_sw;      // [K*6] site wrench f(3) t(3); aliased by gg[nqpad] (gradient out)
-    int32_t c_bw;      // [nab*6] body wrench; aliased by r2[K] (before) and red[2*nqpad] (after)
+    int32_t c_jn;      // [nquat_active] |q| of free/ball quaternions, indexed by JointRec order of quaternion joints
+    int32_t c_sw;      // [K*6] site wrench f(3) t(3), by sorted-site position
+    int32_t c_gg;      // [nqpad] gradient out; aliased by r2[K] (per-site loss terms, consumed earlier)
     int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place)
     int32_t c_kp;      // [3K] keypoints of the current frame
     int32_t chain_stride;
@@ -82,6 +91,7 @@ struct QArgs {
     int32_t root_kp_idx, do_root_opt;
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
     int32_t mb_words;       // LDS words reserved for the per-kind mask bit table (multiple of 4)
+    int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations (A/B switch)
     float tol;
     int32_t maxiter, maxls;
     // outputs
@@ -89,6 +99,7 @@ struct QArgs {
     float *err_out;         // [C,F]      (single: state_out [N,4])
     uint32_t *counters_out; // [C,F,4] or null
     float *q_carry_out;     // [C,nq] or null
+    unsigned long long *prof;  // diagnostic builds (-DSTAC_PROFILE) only: [16] per-phase cycle sums
 };
 
 }  // namespace stac

@@ -8,6 +8,7 @@ PyTorch fallback: without the built extension or without a GPU the constructor r
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -54,7 +55,7 @@ def load_library(path: Path | None = None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    p = Path(path) if path else LIB
+    p = Path(path) if path else Path(os.environ.get("STAC_HIP_LIB", LIB))  # env: diagnostic builds only
     if not p.exists():
         raise StacHipError(f"HIP extension not built: {p} is missing (run `python -m stac_mjx_amd.build`)")
     lib = C.CDLL(str(p))
