@@ -16,7 +16,7 @@
 #include "stac_plan.hpp"
 
 namespace stac {
-hipError_t launch_q_phase(const QArgs &a, int G, int wpb, size_t lds_bytes, hipStream_t s, int *capacity_out);
+hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, size_t lds_bytes, hipStream_t s, int *capacity_out);
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s);
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
@@ -258,25 +258,34 @@ constexpr int kCus = 256;
 
 // Wavefronts per workgroup: the waves of a block share one copy of the plan, so more chains fit the
 // 160 KiB of a CU.  Returns the wpb (1..8) that maximises resident chains per CU for this G.
-static int pick_wpb(const PlanHeader &h, int G, int nkinds, int *waves_per_cu_out) {
-    // LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not fit a CU),
-    // and the kernel's register footprint (> 168 VGPRs) admits 2 waves per SIMD = 8 waves per CU.
+// Launch shape for a given G: wavefronts per workgroup (the waves of a block share one plan copy) and the
+// register-cap variant.  wpe = 2 keeps everything in registers (<= 256 VGPRs, 8 waves per CU); wpe = 4
+// (<= 128 VGPRs, some spills to scratch) admits 16 waves per CU and is used when LDS leaves room for more
+// than 8 waves.  LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not
+// fit a CU).
+struct QShape { int wpb, wpe, waves_per_cu; };
+static QShape pick_shape(const PlanHeader &h, int G, int nkinds) {
     constexpr size_t kGranule = 1280;
-#ifndef STAC_WAVES_BY_REGS
-#define STAC_WAVES_BY_REGS 8
-#endif
-    constexpr int kWavesByRegs = STAC_WAVES_BY_REGS;
-    int best = 0, best_waves = 0;
-    for (int wpb = 1; wpb <= 8; ++wpb) {
-        size_t lds = q_lds_bytes(h, G, nkinds, wpb);
-        if (lds > kLdsPerCu) break;
-        lds = (lds + kGranule - 1) / kGranule * kGranule;
-        int blocks = (int)(kLdsPerCu / lds);
-        if (blocks * wpb > kWavesByRegs) blocks = kWavesByRegs / wpb;  // whole workgroups only
-        const int waves = blocks * wpb;
-        if (waves > best_waves) { best_waves = waves; best = wpb; }  // ties: the smaller workgroup
+    QShape best{0, 2, 0};
+    for (int wpe = 2; wpe <= 4; wpe += 2) {
+        for (int wpb = 1; wpb <= 8; ++wpb) {
+            size_t lds = q_lds_bytes(h, G, nkinds, wpb);
+            if (lds > kLdsPerCu) break;
+            lds = (lds + kGranule - 1) / kGranule * kGranule;
+            int blocks = (int)(kLdsPerCu / lds);
+            if (wpb <= 4) {
+                // up to four waves per workgroup spread over the SIMDs: only the CU total matters
+                if (blocks * wpb > 4 * wpe) blocks = 4 * wpe / wpb;
+            } else {
+                // a bigger workgroup puts ceil(wpb/4) waves on some SIMD; assume the worst stacking
+                const int per_simd = (wpb + 3) / 4;
+                if (blocks * per_simd > wpe) blocks = wpe / per_simd;
+            }
+            const int waves = blocks * wpb;
+            // prefer more resident waves; on ties the variant without spills, then the smaller workgroup
+            if (waves > best.waves_per_cu) best = QShape{wpb, wpe, waves};
+        }
     }
-    if (waves_per_cu_out) *waves_per_cu_out = best_waves;
     return best;
 }
 
@@ -374,16 +383,17 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 }
 
 // Lanes per chain.  Fewer lanes = more chains per wave instruction (throughput); more lanes = fewer
-// idle chains when there are few of them (latency).  Prefer the smallest G whose resident capacity
-// (chains that fit the chip at once) still covers all chains in ONE round with >= 2 waves per SIMD.
+// idle chains when there are few of them (latency).  Take the smallest G in {16, 32, 64} for which the
+// chains fill at least half of that G's resident slots (8 and 4 lanes only on request: with the current
+// LDS footprint they cannot keep two waves per SIMD resident).
 static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     const int cand[] = {16, 32, 64};
     for (int G : cand) {
-        int waves_cu = 0;
-        if (!pick_wpb(m->h, G, nkinds, &waves_cu)) continue;
-        const long capacity = (long)waves_cu * kCus * (64 / G);
-        if (nchains > capacity / 2) return G;  // enough chains to fill at least half the slots of this G
+        const QShape sh = pick_shape(m->h, G, nkinds);
+        if (!sh.wpb) continue;
+        const long capacity = (long)sh.waves_per_cu * kCus * (64 / G);
+        if (nchains > capacity / 2) return G;
     }
     return 64;
 }
@@ -408,17 +418,18 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
     for (; G <= 64; G *= 2) {
-        int wpb = pick_wpb(m->h, G, nkinds, nullptr);
-        if (!wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
-        if (const char *w = getenv("STAC_HIP_WPB")) {  // developer override
+        QShape sh = pick_shape(m->h, G, nkinds);
+        if (!sh.wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
+        if (const char *w = getenv("STAC_HIP_WPB")) {  // developer overrides
             const int ww = atoi(w);
-            if (ww >= 1 && ww <= 8 && q_lds_bytes(m->h, G, nkinds, ww) <= kLdsPerCu) wpb = ww;
+            if (ww >= 1 && ww <= 8 && q_lds_bytes(m->h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
         }
+        if (const char *w = getenv("STAC_HIP_WPE")) sh.wpe = atoi(w) >= 4 ? 4 : 2;
         if (getenv("STAC_HIP_VERBOSE"))
-            fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
-                    nchains, G, wpb, q_lds_bytes(m->h, G, nkinds, wpb), m->h.chain_stride, m->h.total_words);
+            fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
+                    nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(m->h, G, nkinds, sh.wpb), m->h.chain_stride, m->h.total_words);
         a.mb_words = q_mb_words(nkinds, G);
-        e = launch_q_phase(a, G, wpb, q_lds_bytes(m->h, G, nkinds, wpb), s, &cap);
+        e = launch_q_phase(a, G, sh.wpb, sh.wpe, q_lds_bytes(m->h, G, nkinds, sh.wpb), s, &cap);
         if (cap) break;  // an instantiation with this many lanes holds nq
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");
@@ -428,7 +439,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost);
-        static const char *names[] = {"loop", "stage", "fk", "sites", "loss_sum", "wrench", "joint_grad", "trans_sums", "accept_fused", "end_solve", "-", "-"};
+        static const char *names[] = {"loop", "stage", "fk", "sites", "loss_sum", "zero_gg", "joint_grad", "trans_sums", "accept_fused", "end_solve", "-", "-"};
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += h[i];
         fprintf(stderr, "[stac profile] G=%d", G);

@@ -165,15 +165,14 @@ __device__ __forceinline__ void wave_sync() {
 // ------------------------------------------------------------------------------------------------
 // q_phase kernel
 // ------------------------------------------------------------------------------------------------
-#ifndef STAC_WAVES_PER_EU
-#define STAC_WAVES_PER_EU 2
-#endif
 
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast<const int4 *>(p); }
 
-template <int G, int NQR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(STAC_WAVES_PER_EU, STAC_WAVES_PER_EU)))
+// WPE = waves per SIMD the register allocation is capped for (2 -> 256 VGPRs, 4 -> 128 VGPRs): the host
+// picks the variant that lets all chains of a launch be resident at once.
+template <int G, int NQR, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
@@ -784,26 +783,28 @@ __global__ void m_finish_kernel(int K, const float *partial, const float *m0, co
 // ------------------------------------------------------------------------------------------------
 // launchers (called from stac_abi.hip)
 // ------------------------------------------------------------------------------------------------
-template <int G, int NQR>
+template <int G, int NQR, int WPE>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = 64 / G;
     const int per_block = CPW * wpb;
     const int blocks = (a.C + per_block - 1) / per_block;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((q_phase_kernel<G, NQR>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
+    hipLaunchKernelGGL((q_phase_kernel<G, NQR, WPE>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-// nq capacity of an instantiation is G*NQR.  wpb = wavefronts per workgroup (they share the plan copy).
-hipError_t launch_q_phase(const QArgs &a, int G, int wpb, size_t lds_bytes, hipStream_t s, int *capacity_out) {
+// nq capacity of an instantiation is G*NQR.  wpb = wavefronts per workgroup (they share the plan copy),
+// wpe = 2 or 4 (register cap variant).
+hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, size_t lds_bytes, hipStream_t s, int *capacity_out) {
     const int nq = a.h.nq;
     *capacity_out = 0;
-#define STAC_TRY(GG, RR)                                   \
-    if (G == GG && nq <= GG * RR) {                        \
-        *capacity_out = GG * RR;                           \
-        return launch_q<GG, RR>(a, wpb, lds_bytes, s);     \
+#define STAC_TRY(GG, RR)                                                   \
+    if (G == GG && nq <= GG * RR) {                                        \
+        *capacity_out = GG * RR;                                           \
+        return wpe >= 4 ? launch_q<GG, RR, 4>(a, wpb, lds_bytes, s)        \
+                        : launch_q<GG, RR, 2>(a, wpb, lds_bytes, s);       \
     }
     STAC_TRY(4, 20) STAC_TRY(4, 32)
     STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)
