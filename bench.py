@@ -140,6 +140,13 @@ def main():
     achieved = frames_step * bytes_frame / (kern_ms * 1e-3) / 1e9
     # algorithmic flops (full-tree constants): value+grad 17.9 kflop, loss 15.9 kflop
     flops = cnt[2] * 17.9e3 + cnt[1] * 15.9e3
+    traffic = None
+    try:  # HBM bytes per launch measured offline with rocprofv3 PMC passes on this same workload (profiles/)
+        for ent in json.load(open(ROOT / "profiles" / "traffic.json"))["entries"]:
+            if ent["frames"] == frames_step and ent["frames_per_clip"] == F and (args.lanes == 0) == (ent["lanes"] == "auto"):
+                traffic = ent["bytes_per_launch"]
+    except Exception:
+        traffic = None
     line = {
         "metric": "frames/sec STAC pose-fit (rodent, 23 kp)", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -157,7 +164,8 @@ def main():
             "valu_frac_of_fp32_peak": flops / (kern_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "stac::q_phase_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "stac::q_phase_kernel",
+                     "algorithmic_bytes_per_launch": frames_step * bytes_frame,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": bytes_frame},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -648,22 +648,29 @@ void orc_ik_clips(const orc_model *m, const orc_pg_params *p, const float *kp, i
     const int nq = m->nq, K = m->nsite, nb = m->nbody;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    if (nthreads > C) nthreads = C > 0 ? C : 1;
+#pragma omp parallel num_threads(nthreads)
 #endif
-    for (int c = 0; c < C; ++c) {
+    {
+        /* one workspace per thread (not per clip): the CPU baseline should not time malloc */
         ws_t *w = ws_new(m);
         ws_set_bounds(m, w, lb, ub);
         real *qp = (real *)malloc(sizeof(real) * nq);
-        for (int i = 0; i < nq; ++i) qp[i] = q_init ? R(q_init[(size_t)c * nq + i]) : w->qpos0[i];
-        const float *kpc = kp + (size_t)c * F * 3 * K;
-        if (do_root_opt) root_opt_ws(m, w, p, kpc, 0, root_kp_idx, root_dims, trunk_kps, qp, NULL);
-        pose_opt_ws(m, w, p, kpc, F, part_masks, P, qp,
-                    qposes ? qposes + (size_t)c * F * nq : NULL,
-                    xposes ? xposes + (size_t)c * F * nb * 3 : NULL,
-                    xquats ? xquats + (size_t)c * F * nb * 4 : NULL,
-                    markers ? markers + (size_t)c * F * K * 3 : NULL,
-                    frame_error ? frame_error + (size_t)c * F : NULL,
-                    counters ? counters + (size_t)c * F * 4 : NULL);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic)
+#endif
+        for (int c = 0; c < C; ++c) {
+            for (int i = 0; i < nq; ++i) qp[i] = q_init ? R(q_init[(size_t)c * nq + i]) : w->qpos0[i];
+            const float *kpc = kp + (size_t)c * F * 3 * K;
+            if (do_root_opt) root_opt_ws(m, w, p, kpc, 0, root_kp_idx, root_dims, trunk_kps, qp, NULL);
+            pose_opt_ws(m, w, p, kpc, F, part_masks, P, qp,
+                        qposes ? qposes + (size_t)c * F * nq : NULL,
+                        xposes ? xposes + (size_t)c * F * nb * 3 : NULL,
+                        xquats ? xquats + (size_t)c * F * nb * 4 : NULL,
+                        markers ? markers + (size_t)c * F * K * 3 : NULL,
+                        frame_error ? frame_error + (size_t)c * F : NULL,
+                        counters ? counters + (size_t)c * F * 4 : NULL);
+        }
         free(qp);
         ws_free(w);
     }
