@@ -16,7 +16,8 @@
 #include "stac_plan.hpp"
 
 namespace stac {
-hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, size_t lds_bytes, hipStream_t s, int *capacity_out);
+hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
+                          int *capacity_out);
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s);
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
@@ -232,8 +233,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     // per-chain LDS layout
     int o = 0;
     h.c_bx = o; o += (nab + 1) * 7;
-    h.c_ja = o; o += naj * 6;
-    h.c_jq = o; o += has_ball ? naj * 4 : 0;
+    h.c_ja = o; o += naj * 7;
     h.c_jn = o; o += naj;
     o = (o + 3) & ~3;
     h.c_sw = o; o += K * 6;
@@ -264,7 +264,7 @@ constexpr int kCus = 256;
 // than 8 waves.  LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not
 // fit a CU).
 struct QShape { int wpb, wpe, waves_per_cu; };
-static QShape pick_shape(const PlanHeader &h, int G, int nkinds) {
+static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_needed = -1) {
     constexpr size_t kGranule = 1280;
     QShape best{0, 2, 0};
     for (int wpe = 2; wpe <= 4; wpe += 2) {
@@ -284,6 +284,9 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds) {
             const int waves = blocks * wpb;
             // prefer more resident waves; on ties the variant without spills, then the smaller workgroup
             if (waves > best.waves_per_cu) best = QShape{wpb, wpe, waves};
+            // few chains: the first shape that holds every wave at once is enough -- small workgroups spread
+            // over more CUs and the 2-waves-per-SIMD variant does not spill
+            if (waves_needed >= 0 && (long)waves * kCus >= waves_needed) return QShape{wpb, wpe, waves};
         }
     }
     return best;
@@ -417,8 +420,25 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds);
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
-    for (; G <= 64; G *= 2) {
-        QShape sh = pick_shape(m->h, G, nkinds);
+    // Latency mode: when there are so few chains that each would get a whole wavefront anyway (G = 64), let
+    // the wavefront's eight 8-lane groups evaluate the line-search candidates and next momentum points of
+    // that ONE chain speculatively (q_phase_kernel<8, ., ., true>): one trip per iteration instead of three.
+    int spec = (!a.single && p->lanes_per_chain == 0 && G == 64) ? 1 : 0;
+    if (const char *w = getenv("STAC_HIP_SPEC")) spec = a.single ? 0 : atoi(w);
+    if (spec) {
+        QShape sh = pick_shape(m->h, 8, nkinds, nchains);  // 8 groups of 8 lanes: same LDS as eight 8-lane chains
+        if (sh.wpb) {
+            sh.wpe = 2;
+            while (sh.wpb > 1 && q_lds_bytes(m->h, 8, nkinds, sh.wpb) > kLdsPerCu) --sh.wpb;
+            if (getenv("STAC_HIP_VERBOSE"))
+                fprintf(stderr, "[stac] q_phase: chains=%d speculative (1 chain per wavefront) wpb=%d lds=%zu B/block\n",
+                        nchains, sh.wpb, q_lds_bytes(m->h, 8, nkinds, sh.wpb));
+            a.mb_words = q_mb_words(nkinds, 8);
+            e = launch_q_phase(a, 8, sh.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, sh.wpb), s, &cap);
+        }
+    }
+    for (; !cap && G <= 64; G *= 2) {
+        QShape sh = pick_shape(m->h, G, nkinds, ((long)nchains * G + 63) / 64);
         if (!sh.wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
         if (const char *w = getenv("STAC_HIP_WPB")) {  // developer overrides
             const int ww = atoi(w);
@@ -429,7 +449,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
                     nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(m->h, G, nkinds, sh.wpb), m->h.chain_stride, m->h.total_words);
         a.mb_words = q_mb_words(nkinds, G);
-        e = launch_q_phase(a, G, sh.wpb, sh.wpe, q_lds_bytes(m->h, G, nkinds, sh.wpb), s, &cap);
+        e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(m->h, G, nkinds, sh.wpb), s, &cap);
         if (cap) break;  // an instantiation with this many lanes holds nq
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");

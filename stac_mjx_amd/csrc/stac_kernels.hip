@@ -130,7 +130,7 @@ __device__ __forceinline__ float group_tree_sum(const float (&v)[NQR]) {
     return t[0];
 }
 
-enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3 };
+enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4 };
 
 // In-kernel phase stamps: diagnostic build only (-DSTAC_PROFILE -> libstac_hip_prof.so); the stamps
 // go to a buffer of their own and feed no output.  Read the SHARES, not the run time.
@@ -171,9 +171,17 @@ __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast
 
 // WPE = waves per SIMD the register allocation is capped for (2 -> 256 VGPRs, 4 -> 128 VGPRs): the host
 // picks the variant that lets all chains of a launch be resident at once.
-template <int G, int NQR, int WPE>
+//
+// SPEC (latency mode, G == 8 only): the eight lane groups of a wavefront all work on ONE chain.  After a
+// bootstrap evaluation of f, grad f at y, every trip evaluates in parallel the four line-search candidates
+// cand_c = clip(y - (eta / 2^c) g), c = 0..3 (groups 0-3, with gradient) and the four momentum points
+// y_next(c) they would lead to (groups 4-7).  The first acceptable candidate c* is taken exactly as the
+// sequential algorithm would; its gradient gives the stopping residual and group 4+c* already holds
+// f, grad f at the next y: one trip per PG iteration instead of three, identical arithmetic per evaluation.
+template <int G, int NQR, int WPE, bool SPEC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
+    static_assert(!SPEC || G == 8, "speculative mode uses the 8 groups of 8 lanes of one wavefront");
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
     const PlanHeader &H = a.h;
@@ -198,7 +206,7 @@ void q_phase_kernel(const QArgs a) {
         MB[i] = bits;
     }
     float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
-    float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jq = CB + H.c_jq, *jn = CB + H.c_jn;
+    float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn;
     float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
     float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
     __syncthreads();  // the only workgroup-wide barrier: the plan is shared by the block's waves
@@ -209,7 +217,8 @@ void q_phase_kernel(const QArgs a) {
     const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
     // ---- per-chain solver state (uniform inside a group) ------------------------------------------
-    const int chain = (blockIdx.x * wpb + wave) * CPW + grp;
+    const int chain = SPEC ? (blockIdx.x * wpb + wave) : (blockIdx.x * wpb + wave) * CPW + grp;
+    const int role = grp;  // SPEC: 0-3 candidate c, 4-7 momentum point of candidate c
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
     int frame = 0, iter = 0, nls = 0;
@@ -218,7 +227,9 @@ void q_phase_kernel(const QArgs a) {
     uint32_t c_iter = 0, c_ls = 0, c_grad = 0, c_solves = 0;
     uint32_t s_ls = 0, s_grad = 0;  // per-solve counters (single mode)
 
-    float x[NQR], y[NQR], g[NQR], cand[NQR], q0[NQR];
+    float x[NQR], y[NQR], g[NQR], q0[NQR];
+    // the line-search candidate clip(y - eta * g) is recomputed where it is needed (same bits, fewer registers)
+#define CAND(r, e) clipf(FMA(-eta, g[r], y[r]), lbv[e], ubv[e])
     const float eps = 1.1920929e-7f;
 
     // bx[0] = world
@@ -244,7 +255,7 @@ void q_phase_kernel(const QArgs a) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; cand[r] = q0[r]; }
+    for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; }
     wave_sync();
 
     PROF_DECL;
@@ -258,15 +269,26 @@ void q_phase_kernel(const QArgs a) {
         // after every iteration, so the first candidate is almost always rejected and the second
         // accepted: evaluate the gradient together with every candidate after the first.
         const bool ls_with_grad = (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
-        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_with_grad;
+        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_with_grad || (SPEC && st_in == ST_SPEC);
         const bool any_grad = __any(want_grad);
+        // SPEC: this group's candidate scale 2^-c and the momentum coefficient of the running iteration
+        const float spec_pow = SPEC ? ((role & 3) == 0 ? 1.0f : (role & 3) == 1 ? 0.5f : (role & 3) == 2 ? 0.25f : 0.125f) : 1.0f;
+        const float spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
+        const float spec_beta = (t - 1.0f) / spec_tn;
 
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + lg;
             if (e < nq) {
-                const float pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cand[r] : x[r]);
+                float pt;
+                if (SPEC && st_in == ST_SPEC) {
+                    const float ec = eta * spec_pow;  // eta / 2^c (exact)
+                    const float cr = clipf(FMA(-ec, g[r], y[r]), lbv[e], ubv[e]);
+                    pt = role < 4 ? cr : FMA(spec_beta, cr - x[r], cr);
+                } else {
+                    pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? CAND(r, e) : x[r]);
+                }
                 const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
                 qe[e] = (1.0f - mi) * q0[r] + mi * pt;
             }
@@ -298,10 +320,10 @@ void q_phase_kernel(const QArgs a) {
                     const float4 ja4 = lds4(jr + 8);  // axis, slot
                     const int ty = ji.x, ad = ji.y;
                     const V3 jp = {jp4.x, jp4.y, jp4.z}, jax = {ja4.x, ja4.y, ja4.z};
-                    V3 anchor, axis;
+                    V3 anchor;
+                    const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
                     if (ty == JHINGE) {
                         anchor = add3(rotate(jp, quat), pos);
-                        axis = rotate(jax, quat);
                         const float angle = qe[ad] - jp4.w;
                         float sn, cs;
                         sincos_(angle * 0.5f, &sn, &cs);
@@ -311,20 +333,17 @@ void q_phase_kernel(const QArgs a) {
                     } else if (ty == JFREE) {
                         anchor = ld3(qe + ad);
                         pos = anchor;
-                        axis = {0.f, 0.f, 1.f};
                         float n;
                         quat = normalize4(ld4(qe + ad + 3), &n);
                         st4(qe + ad + 3, quat);  // written back, like MJX
                         jn[j] = n;
                     } else if (ty == JSLIDE) {
                         anchor = add3(rotate(jp, quat), pos);
-                        axis = rotate(jax, quat);
+                        const V3 axis = rotate(jax, quat);
                         const float d = qe[ad] - jp4.w;
                         pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
                     } else {  // ball
                         anchor = add3(rotate(jp, quat), pos);
-                        axis = rotate(jax, quat);
-                        if (H.has_ball) st4(jq + 4 * j, quat);
                         float n;
                         const Q4 qloc = normalize4(ld4(qe + ad), &n);
                         st4(qe + ad, qloc);
@@ -332,8 +351,10 @@ void q_phase_kernel(const QArgs a) {
                         quat = qmul(quat, qloc);
                         pos = sub3(anchor, rotate(jp, quat));
                     }
-                    st3(ja + 6 * j, anchor);
-                    st3(ja + 6 * j + 3, axis);
+                    if (any_grad) {
+                        st3(ja + 7 * j, anchor);
+                        st4(ja + 7 * j + 3, prequat);
+                    }
                 }
                 st3(bx + (s + 1) * 7, pos);
                 st4(bx + (s + 1) * 7 + 3, quat);
@@ -426,12 +447,15 @@ void q_phase_kernel(const QArgs a) {
                     Fs = add3(Fs, ld3(sw + 6 * i));
                     T0 = add3(T0, ld3(sw + 6 * i + 3));
                 }
-                const V3 anchor = ld3(ja + 6 * j), axis = ld3(ja + 6 * j + 3);
+                const V3 anchor = ld3(ja + 7 * j);
+                const Q4 prequat = ld4(ja + 7 * j + 3);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
                 if (ty == JHINGE) {
-                    gg[ad] = dot3(axis, tau);
+                    const float4 ja4 = lds4(jr + 8);
+                    gg[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
                 } else if (ty == JSLIDE) {
-                    gg[ad] = dot3(axis, Fs);
+                    const float4 ja4 = lds4(jr + 8);
+                    gg[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), Fs);
                 } else {
                     int qa = ad;
                     V3 tl = tau;
@@ -439,8 +463,7 @@ void q_phase_kernel(const QArgs a) {
                         st3(gg + ad, Fs);
                         qa = ad + 3;
                     } else {
-                        const Q4 pq = ld4(jq + 4 * j);
-                        tl = rotate(tau, Q4{pq.w, -pq.x, -pq.y, -pq.z});
+                        tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});
                     }
                     const Q4 qh = ld4(qe + qa);
                     const V3 u = {qh.x, qh.y, qh.z};
@@ -469,13 +492,9 @@ void q_phase_kernel(const QArgs a) {
             eta = stepsize;
             nls = 0;
 #pragma unroll
-            for (int r = 0; r < NQR; ++r) {
-                const int e = r * G + lg;
-                g[r] = gnew[r];
-                if (e < nq) cand[r] = clipf(FMA(-eta, g[r], y[r]), lbv[e], ubv[e]);
-            }
+            for (int r = 0; r < NQR; ++r) g[r] = gnew[r];
             c_grad++; s_grad++;
-            st = ST_LS;
+            st = SPEC ? ST_SPEC : ST_LS;
         }
         // nq-sums as pairwise trees over the striped registers (oracle: tree_sum); all groups compute
         // them every trip (a few dozen DPP adds), only the groups in the matching state use them
@@ -490,8 +509,13 @@ void q_phase_kernel(const QArgs a) {
                     if (st_in == ST_VG_X) {
                         const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
                         a0 = d * d;
-                    } else {
-                        const float d = cand[r] - y[r];
+                    } else if (st_in == ST_LS) {
+                        const float d = CAND(r, e) - y[r];
+                        a0 = d * d;
+                        a1 = d * g[r];
+                    } else if (SPEC && st_in == ST_SPEC) {
+                        const float ec = eta * spec_pow;
+                        const float d = clipf(FMA(-ec, g[r], y[r]), lbv[e], ubv[e]) - y[r];
                         a0 = d * d;
                         a1 = d * g[r];
                     }
@@ -514,11 +538,6 @@ void q_phase_kernel(const QArgs a) {
             if (!accept) {
                 eta = eta * 0.5f;
                 nls++;
-#pragma unroll
-                for (int r = 0; r < NQR; ++r) {
-                    const int e = r * G + lg;
-                    if (e < nq) cand[r] = clipf(FMA(-eta, g[r], y[r]), lbv[e], ubv[e]);
-                }
                 if (nls >= a.maxls) accept = true;  // taken without evaluation, like jaxopt's loop bound
             }
             if (accept) {
@@ -527,9 +546,11 @@ void q_phase_kernel(const QArgs a) {
                 const float beta = (t - 1.0f) / tn;
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
-                    const float d = cand[r] - x[r];
-                    y[r] = FMA(beta, d, cand[r]);
-                    x[r] = cand[r];
+                    const int e = r * G + lg;
+                    const float cr = e < nq ? CAND(r, e) : x[r];
+                    const float d = cr - x[r];
+                    y[r] = FMA(beta, d, cr);
+                    x[r] = cr;
                 }
                 st = ST_VG_X;
                 fused = ls_with_grad && evaluated_point_accepted;
@@ -561,6 +582,73 @@ void q_phase_kernel(const QArgs a) {
             c_grad++; s_grad++;
             if (error > a.tol && iter < a.maxiter) st = ST_VG_Y;
             else ending = true;
+        }
+
+
+        if (SPEC && __any(st_in == ST_SPEC)) {
+            // (1) which candidate would the sequential line search take?  Candidate n = nls + c is evaluated
+            //     only while n < maxls; candidate n == maxls is taken without evaluation (jaxopt's loop bound).
+            const float ec = eta * spec_pow;
+            const bool ok = !(ec * (loss - fy) > ec * sum1 + 0.5f * sum0 + eps);  // sufficient decrease (own candidate)
+            const bool take = (st_in == ST_SPEC) && role < 4 && (ok || nls + role >= a.maxls);
+            const unsigned long long bal = __ballot(take);
+            if (bal == 0ull) {  // none of the four: halve four more times
+                if (st_in == ST_SPEC) {
+                    eta = eta * 0.0625f;
+                    nls += 4;
+                    c_ls += 4; s_ls += 4;
+                }
+            } else {
+                const int cs = (__ffsll((long long)bal) - 1) >> 3;  // first accepting group = c*
+                const int evaluated = (nls + cs >= a.maxls) ? cs : cs + 1;
+                const float pw = cs == 0 ? 1.0f : cs == 1 ? 0.5f : cs == 2 ? 0.25f : 0.125f;
+                const float eacc = eta * pw;
+                // (2) stopping residual from the gradient at the accepted candidate (group c*)
+                float t0[NQR];
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    float a0 = 0.0f;
+                    if (e < nq) {
+                        const float xr = clipf(FMA(-eacc, g[r], y[r]), lbv[e], ubv[e]);
+                        const float d = clipf(xr - gnew[r], lbv[e], ubv[e]) - xr;
+                        a0 = d * d;
+                    }
+                    t0[r] = a0;
+                }
+                const float e2_own = group_tree_sum<G, NQR>(t0);
+                const float e2 = __shfl(e2_own, cs * 8, 64);
+                const float fx_c = __shfl(loss, cs * 8, 64);
+                // (3) f, grad f at the next momentum point come from group 4 + c*
+                const float fy_next = __shfl(loss, (4 + cs) * 8, 64);
+                float gnext[NQR];
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) gnext[r] = __shfl(gnew[r], (4 + cs) * 8 + lg, 64);
+                if (st_in == ST_SPEC) {
+                    c_ls += evaluated; s_ls += evaluated;
+                    c_grad += 1; s_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
+                    next_step = (eacc <= 1e-6f) ? 1.0f : eacc / 0.5f;
+#pragma unroll
+                    for (int r = 0; r < NQR; ++r) {
+                        const int e = r * G + lg;
+                        const float cr = e < nq ? clipf(FMA(-eacc, g[r], y[r]), lbv[e], ubv[e]) : x[r];
+                        const float d = cr - x[r];
+                        y[r] = FMA(spec_beta, d, cr);
+                        x[r] = cr;
+                        g[r] = gnext[r];
+                    }
+                    fx = fx_c;
+                    error = __builtin_sqrtf(e2);
+                    stepsize = next_step;
+                    t = spec_tn;
+                    iter++;
+                    fy = fy_next;
+                    eta = stepsize;
+                    nls = 0;
+                    if (!(error > a.tol && iter < a.maxiter)) ending = true;
+                    else { c_grad += 1; s_grad += 1; }  // f, grad f at the next y: already evaluated (group 4 + c*)
+                }
+            }
         }
 
         PROF_TICK(8);  // accept / fused residual
@@ -614,8 +702,9 @@ void q_phase_kernel(const QArgs a) {
                     kind++;
                     if (kind > a.P + 2) {  // frame finished: record it (compute_stac.py:261-267)
                         const size_t fo = (size_t)chain * a.F + frame;
-                        for (int e = lg; e < nq; e += G) a.qpos_out[fo * nq + e] = qe[e];
-                        if (lg == 0) {
+                        if (!SPEC || role == 0)
+                            for (int e = lg; e < nq; e += G) a.qpos_out[fo * nq + e] = qe[e];
+                        if (lg == 0 && (!SPEC || role == 0)) {
                             a.err_out[fo] = error;
                             if (a.counters_out) {
                                 uint32_t *co = a.counters_out + fo * 4;
@@ -626,7 +715,7 @@ void q_phase_kernel(const QArgs a) {
                         frame++;
                         kind = 2;
                         if (frame >= a.F) {
-                            if (a.q_carry_out)
+                            if (a.q_carry_out && (!SPEC || role == 0))
                                 for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
                             st = ST_DONE;
                         } else {
@@ -783,28 +872,40 @@ __global__ void m_finish_kernel(int K, const float *partial, const float *m0, co
 // ------------------------------------------------------------------------------------------------
 // launchers (called from stac_abi.hip)
 // ------------------------------------------------------------------------------------------------
-template <int G, int NQR, int WPE>
+template <int G, int NQR, int WPE, bool SPEC>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
-    constexpr int CPW = 64 / G;
+    constexpr int CPW = SPEC ? 1 : 64 / G;
     const int per_block = CPW * wpb;
     const int blocks = (a.C + per_block - 1) / per_block;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((q_phase_kernel<G, NQR, WPE>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
+    hipLaunchKernelGGL((q_phase_kernel<G, NQR, WPE, SPEC>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
     return hipGetLastError();
 }
 
 // nq capacity of an instantiation is G*NQR.  wpb = wavefronts per workgroup (they share the plan copy),
-// wpe = 2 or 4 (register cap variant).
-hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, size_t lds_bytes, hipStream_t s, int *capacity_out) {
+// wpe = 2 or 4 (register cap variant), spec = latency mode (G must be 8).
+hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
+                          int *capacity_out) {
     const int nq = a.h.nq;
     *capacity_out = 0;
-#define STAC_TRY(GG, RR)                                                   \
-    if (G == GG && nq <= GG * RR) {                                        \
-        *capacity_out = GG * RR;                                           \
-        return wpe >= 4 ? launch_q<GG, RR, 4>(a, wpb, lds_bytes, s)        \
-                        : launch_q<GG, RR, 2>(a, wpb, lds_bytes, s);       \
+    if (spec) {
+        if (G != 8) return hipErrorInvalidValue;
+#define STAC_TRY_SPEC(RR)                                            \
+    if (nq <= 8 * RR) {                                              \
+        *capacity_out = 8 * RR;                                      \
+        return launch_q<8, RR, 2, true>(a, wpb, lds_bytes, s);       \
+    }
+        STAC_TRY_SPEC(10) STAC_TRY_SPEC(16) STAC_TRY_SPEC(32)
+#undef STAC_TRY_SPEC
+        return hipErrorInvalidValue;
+    }
+#define STAC_TRY(GG, RR)                                                          \
+    if (G == GG && nq <= GG * RR) {                                               \
+        *capacity_out = GG * RR;                                                  \
+        return wpe >= 4 ? launch_q<GG, RR, 4, false>(a, wpb, lds_bytes, s)        \
+                        : launch_q<GG, RR, 2, false>(a, wpb, lds_bytes, s);       \
     }
     STAC_TRY(4, 20) STAC_TRY(4, 32)
     STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)

@@ -56,8 +56,7 @@ struct PlanHeader {
     int32_t total_words;
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
     int32_t c_bx;      // [(nab+1)*7] pos(3) quat(4); entry 0 = world
-    int32_t c_ja;      // [naj*6] anchor(3) axis(3)
-    int32_t c_jq;      // [naj*4] quaternion before a ball joint (only if has_ball)
+    int32_t c_ja;      // [naj*7] anchor(3) + quaternion before the joint(4) (the joint pass rotates the axis)
     int32_t c_jn;      // [nquat_active] |q| of free/ball quaternions, indexed by JointRec order of quaternion joints
     int32_t c_sw;      // [K*6] site wrench f(3) t(3), by sorted-site position
     int32_t c_gg;      // [nqpad] gradient out; aliased by r2[K] (per-site loss terms, consumed earlier)
