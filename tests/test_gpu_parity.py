@@ -140,6 +140,41 @@ def test_q_phase_no_parts_and_tight_iteration_cap(rodent_setup, rodent_mocap):
     assert (ref["counters"][..., 0] == 7).all()
 
 
+@pytest.mark.parametrize("spec", ["0", "1"])
+@pytest.mark.parametrize("maxls", [2, 3, 15])
+def test_q_phase_line_search_bounds_and_speculative_mode(rodent_setup, rodent_mocap, monkeypatch, spec, maxls):
+    """Small maxls exercises jaxopt's loop bound (a candidate taken WITHOUT evaluation); STAC_HIP_SPEC forces
+    the speculative latency kernel (8 lane groups on one chain) on or off -- both must equal the oracle."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    monkeypatch.setenv("STAC_HIP_SPEC", spec)
+    fs = rodent_setup
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=40, maxls=maxls)
+    orc = Oracle(fs.tables, tol=1e-4, maxiter=40, maxls=maxls)
+    kp = rodent_mocap[400:406].reshape(3, 2, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(res, ref)
+
+
+def test_speculative_mode_long_chain_matches_normal_mode(rodent_setup, rodent_mocap, monkeypatch):
+    """One 12-frame warm-started chain: speculative kernel == regular kernel == oracle, bit for bit."""
+    fs = rodent_setup
+    kp = rodent_mocap[:12][None]
+    outs = []
+    for spec in ("0", "1"):
+        monkeypatch.setenv("STAC_HIP_SPEC", spec)
+        eng = _engine(fs)
+        outs.append(eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                                root_dims=fs.root_dims, do_root_opt=True))
+    for k in ("qpos", "frame_error", "counters", "marker_sites", "xquat", "carry_qpos"):
+        assert (outs[0][k] == outs[1][k]).all(), k
+    ref = _oracle(fs).ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(outs[1], ref)
+
+
 def test_q_phase_fruitfly_model(fly_setup):
     """Different tree (quat-oriented bodies, nq=43, K=30, 6 part groups, no root optimisation)."""
     fs = fly_setup
