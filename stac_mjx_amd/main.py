@@ -24,7 +24,7 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
 
     Returns ``(fit_offsets_path, ik_only_path or None)``.  Raises ``ValueError`` when ``kp_data`` columns
     do not match ``3 * len(kp_names)`` or ``n_frames_per_clip`` does not divide the frame count.
-    ``infer_qvels`` (post-processing) is not part of the hot path and is left empty.
+    ``infer_qvels`` runs the reference's finite-difference post-processing on the host.
     """
     base_path = Path.cwd() if base_path is None else Path(base_path)
     kp_data = np.asarray(kp_data)
@@ -62,6 +62,10 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
     if cfg.stac.continuous:
         ik_data = utils.handle_edge_effects(ik_data, cfg.stac.n_frames_per_clip)
     print(f"Final qpos shape: {ik_data.qpos.shape}")
+    if cfg.stac.infer_qvels:  # main.py:118-133: per clip of n_frames_per_clip frames
+        batched = ik_data.qpos.reshape((-1, cfg.stac.n_frames_per_clip, ik_data.qpos.shape[-1]))
+        qvels = [utils.compute_velocity_from_kinematics(c, dt=stac._timestep, freejoint=stac._freejoint) for c in batched]
+        ik_data.qvel = np.stack(qvels).reshape(-1, qvels[0].shape[-1])
     ik_only_path = io.save_data_to_h5(config=cfg, file_path=ik_only_path, **ik_data.as_dict())
     print(f"Saved ik_only to {ik_only_path}. Finished in {(time.time() - start) / 60:.2f} minutes")
     return fit_offsets_path, ik_only_path

@@ -95,3 +95,55 @@ def handle_edge_effects(ik_only_data, n_frames_per_clip: int):
     for name in ("qpos", "kp_data", "xpos", "xquat", "marker_sites"):
         setattr(ik_only_data, name, f(getattr(ik_only_data, name)))
     return ik_only_data
+
+
+# ---- quaternion helpers and velocity inference (stac_mjx/utils.py:172-347) -- post-processing, host numpy ----
+_TOL = 1e-10
+
+
+def quat_mul(quat1, quat2):
+    """Hamilton product, any leading batch dims (utils.py:196-218)."""
+    a, b = np.asarray(quat1), np.asarray(quat2)
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], axis=-1)  # fmt: skip
+
+
+def quat_conj(quat):
+    """[w, -i, -j, -k] (utils.py:240-256)."""
+    q = np.asarray(quat)
+    return np.stack([q[..., 0], -q[..., 1], -q[..., 2], -q[..., 3]], axis=-1)
+
+
+def quat_diff(source, target):
+    """Rotation from source to target (utils.py:259-274)."""
+    return quat_mul(quat_conj(source), target)
+
+
+def quat_to_axisangle(quat):
+    """Axis-angle vector, angle encoded by its length (utils.py:277-299); batched over leading dims."""
+    q = np.asarray(quat, dtype=np.float64)
+    angle = 2 * np.arccos(np.clip(q[..., 0], -1.0, 1.0))
+    small = angle < _TOL
+    qn = np.where(small, 1.0, np.sin(angle / 2))
+    wrapped = (angle + np.pi) % (2 * np.pi) - np.pi
+    out = q[..., 1:4] / qn[..., None] * wrapped[..., None]
+    return np.where(small[..., None], 0.0, out).astype(np.asarray(quat).dtype)
+
+
+def compute_velocity_from_kinematics(qpos_trajectory, dt: float, freejoint: bool = True, max_qvel: float = 20.0):
+    """Finite-difference qvel of one continuous clip (utils.py:302-347): last frame repeated, root gyro from the
+    normalised quaternion difference, joint velocities clipped to +-max_qvel."""
+    q = np.asarray(qpos_trajectory)
+    q = np.concatenate([q, q[-1:]], axis=0)
+    if not freejoint:
+        return np.clip((q[1:] - q[:-1]) / dt, -max_qvel, max_qvel)
+    qvel_joints = (q[1:, 7:] - q[:-1, 7:]) / dt
+    qvel_translation = (q[1:, :3] - q[:-1, :3]) / dt
+    diff = quat_diff(q[:-1, 3:7], q[1:, 3:7])
+    diff = diff / np.linalg.norm(diff, axis=-1, keepdims=True)
+    qvel_gyro = quat_to_axisangle(diff) / dt
+    out = np.concatenate([qvel_translation, qvel_gyro, qvel_joints], axis=1)
+    out[:, 6:] = np.clip(out[:, 6:], -max_qvel, max_qvel)
+    return out.astype(q.dtype)

@@ -112,13 +112,14 @@ def test_run_stac_end_to_end(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
     from stac_mjx_amd.io import load_stac_data
     from stac_mjx_amd.main import run_stac
 
-    cfg = _cfg(rodent_cfg, n_fit_frames=4, n_frames_per_clip=2)
+    cfg = _cfg(rodent_cfg, n_fit_frames=4, n_frames_per_clip=2, infer_qvels=True)
     cfg.model.N_ITERS = 1
     kp = rodent_mocap[:8]
     fit_path, ik_path = run_stac(cfg, kp, rodent_setup.kp_names, base_path=tmp_path, setup=rodent_setup)
     _, fit = load_stac_data(fit_path)
     _, ik = load_stac_data(ik_path)
     assert fit.qpos.shape == (4, 74) and ik.qpos.shape == (8, 74) and ik.xquat.shape == (8, 67, 4)
+    assert ik.qvel.shape == (8, 73) and np.isfinite(ik.qvel).all() and np.abs(ik.qvel[:, 6:]).max() <= 20.0
     np.testing.assert_array_equal(ik.offsets, fit.offsets)
     with pytest.raises(ValueError, match="n_frames_per_clip"):
         cfg3 = _cfg(rodent_cfg, n_fit_frames=4, n_frames_per_clip=3, skip_fit_offsets=True)

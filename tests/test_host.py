@@ -289,3 +289,30 @@ def test_run_stac_validates_columns_before_touching_the_gpu(tmp_path, rodent_cfg
     cfg = validate_config({"model": rodent_cfg, "stac": stac})
     with pytest.raises(ValueError, match="columns"):
         run_stac(cfg, np.zeros((4, 68), np.float32), ["k"] * 23, base_path=tmp_path)
+
+
+# ---- quaternion / velocity post-processing (tests/unit/test_utils_math.py restated) ------------------------------------
+def test_quat_helpers_and_velocity():
+    from stac_mjx_amd import utils
+
+    q = np.array([0.5, 0.5, 0.5, 0.5])
+    assert np.allclose(utils.quat_mul(np.array([1.0, 0, 0, 0]), q), q)
+    assert np.allclose(utils.quat_conj(q), [0.5, -0.5, -0.5, -0.5])
+    assert np.allclose(utils.quat_diff(q, q), [1.0, 0, 0, 0])
+    ang = np.pi / 2
+    assert np.allclose(utils.quat_to_axisangle(np.array([np.cos(ang / 2), np.sin(ang / 2), 0.0, 0.0])), [ang, 0, 0])
+    assert np.allclose(utils.quat_to_axisangle(np.array([1.0, 0, 0, 0])), 0.0)
+    qpos = np.array([[0.0, 0, 0], [1.0, 2, 3], [2.0, 4, 6]])
+    qvel = utils.compute_velocity_from_kinematics(qpos, dt=1.0, freejoint=False, max_qvel=100.0)
+    assert qvel.shape == (3, 3) and np.allclose(qvel[0], [1, 2, 3]) and np.allclose(qvel[1], [1, 2, 3]) and np.allclose(qvel[2], 0)
+    # free joint: constant yaw rate about z, translation along x, one hinge
+    T, dt, w = 6, 0.01, 2.0
+    tt = np.arange(T) * dt
+    qp = np.zeros((T, 8))
+    qp[:, 0] = 3.0 * tt
+    qp[:, 3], qp[:, 6] = np.cos(w * tt / 2), np.sin(w * tt / 2)
+    qp[:, 7] = 1000.0 * tt  # exceeds max_qvel -> clipped
+    v = utils.compute_velocity_from_kinematics(qp, dt=dt, freejoint=True)
+    assert v.shape == (T, 7)
+    assert np.allclose(v[:-1, 0], 3.0) and np.allclose(v[:-1, 3:6], [0, 0, w], atol=1e-6)
+    assert np.allclose(v[:-1, 6], 20.0) and np.allclose(v[-1], 0.0)
