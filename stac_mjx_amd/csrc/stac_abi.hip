@@ -52,6 +52,7 @@ struct stac_model {
     int32_t *d_site_bodyid = nullptr;
     float *d_site_pos = nullptr;  // [K,3] offsets for the stand-alone FK / m-phase kernels (mirrors the plan's SiteRec.pos)
     uint8_t *d_masks = nullptr;  // [kMaxKinds, nqpad] + [K] + [3K]
+    std::vector<uint8_t> masks_cache;  // what d_masks currently holds (uploads + their sync happen only on change)
     size_t masks_bytes = 0;
     float *d_scratch = nullptr;  // grown on demand (xpos/xquat when the caller does not want them)
     size_t scratch_floats = 0;
@@ -479,13 +480,17 @@ extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, co
     if (N == 0) return STAC_OK;
     hipStream_t s = (hipStream_t)stream;
     const int nqpad = m->h.nqpad, K = m->h.K, nq = m->h.nq;
-    std::vector<uint8_t> hostm((size_t)nqpad + 3 * K, 0);
+    std::vector<uint8_t> hostm((size_t)nqpad + 3 * K + 1, 0);
     std::memcpy(hostm.data(), qs_to_opt, nq);
     std::memcpy(hostm.data() + nqpad, kps_to_opt, 3 * K);
+    hostm.back() = 0xA5;  // tag: single-solve layout
     uint8_t *d_kpw3 = m->d_masks + (size_t)kMaxKinds * nqpad + K;
-    HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), nqpad, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_kpw3, hostm.data() + nqpad, 3 * K, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
+    if (hostm != m->masks_cache) {
+        HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), nqpad, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_kpw3, hostm.data() + nqpad, 3 * K, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
+        m->masks_cache = hostm;
+    }
     QArgs a{};
     a.kp = kp; a.q_init = q0; a.masks = m->d_masks; a.kpw = nullptr; a.kpw3 = d_kpw3;
     a.C = N; a.F = 1; a.P = 0; a.root_kp_idx = 0; a.do_root_opt = 0; a.single = 1;
@@ -517,9 +522,13 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     for (int pi = 0; pi < P; ++pi) std::memcpy(hostm.data() + (size_t)(3 + pi) * nqpad, part_masks + (size_t)pi * nq, nq);
     uint8_t *d_kpw = m->d_masks + (size_t)kMaxKinds * nqpad;
     for (int k = 0; k < K; ++k) hostm[(size_t)(P + 3) * nqpad + k] = (trunk_kps && trunk_kps[k]) ? 1 : 0;
-    HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), (size_t)(P + 3) * nqpad, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_kpw, hostm.data() + (size_t)(P + 3) * nqpad, K, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
+    hostm.push_back(0x5A);  // tag: phase layout
+    if (hostm != m->masks_cache) {
+        HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), (size_t)(P + 3) * nqpad, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_kpw, hostm.data() + (size_t)(P + 3) * nqpad, K, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
+        m->masks_cache = hostm;
+    }
     QArgs a{};
     a.kp = kp; a.q_init = q_init; a.masks = m->d_masks; a.kpw = d_kpw; a.kpw3 = nullptr;
     a.C = C; a.F = F; a.P = P; a.root_kp_idx = root_kp_idx; a.do_root_opt = do_root_opt ? 1 : 0; a.single = 0;

@@ -222,10 +222,9 @@ void q_phase_kernel(const QArgs a) {
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
     int frame = 0, iter = 0, nls = 0;
-    float stepsize = 1.0f, t = 1.0f, tn = 1.0f, next_step = 1.0f, eta = 1.0f, fy = 0.0f, fx = 0.0f;
+    float stepsize = 1.0f, t = 1.0f, eta = 1.0f, fy = 0.0f, fx = 0.0f;
     float error = __builtin_inff();
     uint32_t c_iter = 0, c_ls = 0, c_grad = 0, c_solves = 0;
-    uint32_t s_ls = 0, s_grad = 0;  // per-solve counters (single mode)
 
     float x[NQR], y[NQR], g[NQR], q0[NQR];
     // the line-search candidate clip(y - eta * g) is recomputed where it is needed (same bits, fewer registers)
@@ -271,7 +270,8 @@ void q_phase_kernel(const QArgs a) {
         const bool ls_with_grad = (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
         const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_with_grad || (SPEC && st_in == ST_SPEC);
         const bool any_grad = __any(want_grad);
-        // SPEC: this group's candidate scale 2^-c and the momentum coefficient of the running iteration
+        // t_next and the momentum coefficient of the running iteration (functions of t only; recomputed every
+        // trip instead of being carried); SPEC: this group's candidate scale 2^-c
         const float spec_pow = SPEC ? ((role & 3) == 0 ? 1.0f : (role & 3) == 1 ? 0.5f : (role & 3) == 2 ? 0.25f : 0.125f) : 1.0f;
         const float spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
         const float spec_beta = (t - 1.0f) / spec_tn;
@@ -493,7 +493,7 @@ void q_phase_kernel(const QArgs a) {
             nls = 0;
 #pragma unroll
             for (int r = 0; r < NQR; ++r) g[r] = gnew[r];
-            c_grad++; s_grad++;
+            c_grad++;
             st = SPEC ? ST_SPEC : ST_LS;
         }
         // nq-sums as pairwise trees over the striped registers (oracle: tree_sum); all groups compute
@@ -530,7 +530,7 @@ void q_phase_kernel(const QArgs a) {
         bool ending = false;
         bool fused = false;  // accepted a candidate whose gradient is already in gnew
         if (st_in == ST_LS) {
-            c_ls++; s_ls++;
+            c_ls++;
             const float lhs = eta * (loss - fy);
             const float rhs = eta * sum1 + 0.5f * sum0 + eps;
             bool accept = !(lhs > rhs);
@@ -541,9 +541,7 @@ void q_phase_kernel(const QArgs a) {
                 if (nls >= a.maxls) accept = true;  // taken without evaluation, like jaxopt's loop bound
             }
             if (accept) {
-                next_step = (eta <= 1e-6f) ? 1.0f : eta / 0.5f;
-                tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
-                const float beta = (t - 1.0f) / tn;
+                const float beta = spec_beta;  // (t - 1) / t_next of the running iteration
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
@@ -576,10 +574,10 @@ void q_phase_kernel(const QArgs a) {
         if (st_in == ST_VG_X || fused) {
             fx = loss;
             error = __builtin_sqrtf(sum0);
-            stepsize = next_step;
-            t = tn;
+            stepsize = (eta <= 1e-6f) ? 1.0f : eta / 0.5f;  // eta still holds the accepted step
+            t = spec_tn;
             iter++;
-            c_grad++; s_grad++;
+            c_grad++;
             if (error > a.tol && iter < a.maxiter) st = ST_VG_Y;
             else ending = true;
         }
@@ -596,7 +594,7 @@ void q_phase_kernel(const QArgs a) {
                 if (st_in == ST_SPEC) {
                     eta = eta * 0.0625f;
                     nls += 4;
-                    c_ls += 4; s_ls += 4;
+                    c_ls += 4;
                 }
             } else {
                 const int cs = (__ffsll((long long)bal) - 1) >> 3;  // first accepting group = c*
@@ -625,9 +623,9 @@ void q_phase_kernel(const QArgs a) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) gnext[r] = __shfl(gnew[r], (4 + cs) * 8 + lg, 64);
                 if (st_in == ST_SPEC) {
-                    c_ls += evaluated; s_ls += evaluated;
-                    c_grad += 1; s_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
-                    next_step = (eacc <= 1e-6f) ? 1.0f : eacc / 0.5f;
+                    c_ls += evaluated;
+                    c_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
+                    const float next_step = (eacc <= 1e-6f) ? 1.0f : eacc / 0.5f;
 #pragma unroll
                     for (int r = 0; r < NQR; ++r) {
                         const int e = r * G + lg;
@@ -646,7 +644,7 @@ void q_phase_kernel(const QArgs a) {
                     eta = stepsize;
                     nls = 0;
                     if (!(error > a.tol && iter < a.maxiter)) ending = true;
-                    else { c_grad += 1; s_grad += 1; }  // f, grad f at the next y: already evaluated (group 4 + c*)
+                    else { c_grad += 1; }  // f, grad f at the next y: already evaluated (group 4 + c*)
                 }
             }
         }
@@ -685,7 +683,7 @@ void q_phase_kernel(const QArgs a) {
                         so[0] = error; so[1] = stepsize; so[2] = t; so[3] = fx;
                         if (a.counters_out) {
                             uint32_t *co = a.counters_out + (size_t)chain * 4;
-                            co[0] = (uint32_t)iter; co[1] = s_ls; co[2] = s_grad; co[3] = 1u;
+                            co[0] = (uint32_t)iter; co[1] = c_ls; co[2] = c_grad; co[3] = 1u;
                         }
                     }
                     st = ST_DONE;
@@ -731,7 +729,7 @@ void q_phase_kernel(const QArgs a) {
                     if (st != ST_DONE) {
 #pragma unroll
                         for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; }
-                        stepsize = 1.0f; t = 1.0f; iter = 0; s_ls = 0; s_grad = 0;
+                        stepsize = 1.0f; t = 1.0f; iter = 0;
                         error = __builtin_inff();
                         st = ST_VG_Y;
                     }

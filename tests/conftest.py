@@ -64,6 +64,17 @@ def fly_setup():
 
 
 @pytest.fixture(scope="session")
+def mouse_setup():
+    from stac_mjx_amd.fit_model import finish_fit_setup
+    from stac_mjx_amd.mjcf import ModelTables
+
+    with open(GOLDEN / "mouse_model_cfg.json") as fh:
+        cfg = json.load(fh)
+    tables = ModelTables.load(GOLDEN / "mouse_tables.npz")
+    return finish_fit_setup(tables, cfg, list(cfg["KEYPOINT_MODEL_PAIRS"].keys()))
+
+
+@pytest.fixture(scope="session")
 def demo_viz():
     with np.load(GOLDEN / "demo_viz_golden.npz") as d:
         return {k: d[k] for k in d.files}

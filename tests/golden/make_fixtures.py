@@ -20,6 +20,8 @@ Fixtures are DATA only (inputs / expected outputs / compiled model tables), no r
                             float32 [1000, 69] metres, KEYPOINT_MODEL_PAIRS order.
   fly_tables.npz / fly_model_cfg.json
                             fruitfly_force_free.xml + configs/model/fly_tethered.yaml (BASELINE config 5).
+  mouse_tables.npz / mouse_model_cfg.json
+                            mouse_with_meshes.xml + configs/model/mouse.yaml (nq = 230, K = 34).
   oracle_regress.npz        outputs of THIS repo's oracle on a few real frames (regression pin of the
                             oracle itself; not a reference pin).
 """
@@ -102,6 +104,13 @@ def main():
     fs.tables.save(HERE / "fly_tables.npz")
     with open(HERE / "fly_model_cfg.json", "w") as fh:
         json.dump(fly, fh, indent=1)
+
+    # 4b. mouse (nq = 230, 225 bodies, K = 34: stresses level count, nq capacity and the > 32-site loss tree)
+    mouse = yaml.safe_load(open(ref / "configs" / "model" / "mouse.yaml"))
+    mouse_names = list(mouse["KEYPOINT_MODEL_PAIRS"].keys())
+    build_fit_setup(ref / mouse["MJCF_PATH"], mouse, mouse_names).tables.save(HERE / "mouse_tables.npz")
+    with open(HERE / "mouse_model_cfg.json", "w") as fh:
+        json.dump(mouse, fh, indent=1)
 
     # 5. oracle regression pin -------------------------------------------------------------------
     from oracle import Oracle

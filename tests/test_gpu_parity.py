@@ -189,6 +189,25 @@ def test_q_phase_fruitfly_model(fly_setup):
     _compare_phase(res, ref)
 
 
+@pytest.mark.parametrize("lanes", [0, 16, 64])
+def test_q_phase_mouse_model(mouse_setup, lanes):
+    """Mouse: nq = 230, 181 active bodies on 85 tree levels, K = 34 (> 32-site loss tree), no part
+    groups; lanes = 0 takes the speculative latency kernel (3 chains), 16 / 64 the regular one."""
+    fs = mouse_setup
+    assert fs.tables.nq == 230 and fs.tables.nsite == 34 and fs.part_masks.shape[0] == 0
+    eng, orc = _engine(fs, maxiter=25, lanes_per_chain=lanes), _oracle(fs, maxiter=25)
+    rng = np.random.default_rng(4)
+    qt = fs.tables.qpos0[None] + np.clip(rng.normal(0, 0.05, (3, 230)), -0.1, 0.1).astype(np.float32)
+    qt[:, 3:7] = fs.tables.qpos0[3:7]
+    kp = np.stack([orc.fk(q)["site_xpos"].reshape(-1) for q in qt]).reshape(3, 1, 102)
+    kp = kp + rng.normal(0, 5e-4, kp.shape).astype(np.float32)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=fs.do_root_opt)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims,
+                       do_root_opt=fs.do_root_opt)
+    _compare_phase(res, ref)
+
+
 def test_q_phase_ball_and_slide_joints():
     from stac_mjx_amd.fit_model import FitSetup
     from stac_mjx_amd.mjcf import align_joint_dims, compile_mjcf
