@@ -31,13 +31,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
-def load_setup():
+def load_setup(model="rodent"):
     from stac_mjx_amd.fit_model import finish_fit_setup
     from stac_mjx_amd.mjcf import ModelTables
 
     g = ROOT / "tests" / "golden"
-    cfg = json.load(open(g / "rodent_model_cfg.json"))
-    fs = finish_fit_setup(ModelTables.load(g / "rodent_tables.npz"), cfg, list(cfg["KEYPOINT_MODEL_PAIRS"].keys()))
+    cfg = json.load(open(g / f"{model}_model_cfg.json"))
+    fs = finish_fit_setup(ModelTables.load(g / f"{model}_tables.npz"), cfg, list(cfg["KEYPOINT_MODEL_PAIRS"].keys()))
     return fs, cfg
 
 
@@ -51,8 +51,8 @@ def cpu_baseline(fs, cfg, kp_host, target_s=15.0):
 
     def run(n):
         t0 = time.perf_counter()
-        orc.ik_clips(kp_host[:n], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims,
-                     do_root_opt=True, want_bodies=False)
+        orc.ik_clips(kp_host[:n], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, max(fs.root_kp_idx, 0), fs.root_dims,
+                     do_root_opt=fs.do_root_opt, want_bodies=False)
         return time.perf_counter() - t0
 
     n0 = min(C, max(cores * 2, 1))
@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--frames-per-clip", type=int, default=1)
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solver", default="pg", choices=["pg", "lm"],
+                    help="pg = the reference's projected gradient (parity mode, the BASELINE metric); lm = optional fast solver")
+    ap.add_argument("--model", default="rodent", choices=["rodent", "fly", "mouse"],
+                    help="rodent = the BASELINE metric; fly / mouse = other fixtures (reported under config, not the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,11 +96,11 @@ def main():
     from stac_mjx_amd.engine import Engine
     from stac_mjx_amd.synth import synth_keypoints, synth_offsets
 
-    fs, cfg = load_setup()
+    fs, cfg = load_setup(args.model)
     F = args.frames_per_clip
     C = args.frames // F
     eng = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), lanes_per_chain=args.lanes,
-                 device=f"cuda:{local_rank}")
+                 device=f"cuda:{local_rank}", solver=args.solver)
     # synthetic batch (seeded per rank), generated with the engine's own FK, then offsets fixed
     eng.set_site_pos(synth_offsets(fs))
     fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
@@ -107,7 +111,8 @@ def main():
     def step():
         nonlocal out
         out = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                          root_dims=fs.root_dims, do_root_opt=True, want_bodies=False, want_markers=False, out=out)
+                          root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False,
+                          out=out)
 
     for _ in range(args.warmup):
         step()
@@ -148,13 +153,16 @@ def main():
     except Exception:
         traffic = None
     line = {
-        "metric": "frames/sec STAC pose-fit (rodent, 23 kp)", "value": value, "unit": "frames/s",
+        "metric": "frames/sec STAC pose-fit (rodent, 23 kp)" if args.model == "rodent" else f"frames/sec STAC pose-fit ({args.model}, {fs.tables.nsite} kp)",
+        "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[1]: rodent.xml, 23 keypoints, {frames_step} synthetic frames per GPU, "
-                        f"q_phase only (root opt + full + 5 part PG solves per frame), n_frames_per_clip={F} "
-                        f"({C} independent chains), FTOL={cfg['FTOL']}, N_ITER_Q={cfg['N_ITER_Q']}, solver=pg (parity mode)",
+            "workload": f"{'BASELINE configs[1]: rodent.xml' if args.model == 'rodent' else args.model + ' model'}, "
+                        f"{fs.tables.nsite} keypoints, {frames_step} synthetic frames per GPU, "
+                        f"q_phase only ({'root opt + ' if fs.do_root_opt else ''}full + {len(fs.part_masks)} part PG solves per frame), n_frames_per_clip={F} "
+                        f"({C} independent chains), FTOL={cfg['FTOL']}, N_ITER_Q={cfg['N_ITER_Q']}, "
+                        + ("solver=pg (parity mode)" if args.solver == "pg" else "solver=lm (NOT the reference's algorithm; marker-space quality only)"),
             "frames_per_gpu": frames_step, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
             "parallelism": f"clips sharded over {world} GPU(s), no data-path collective",
             "iters_per_frame": cnt[0] / frames_step, "ls_evals_per_frame": cnt[1] / frames_step,
@@ -168,7 +176,7 @@ def main():
                      "algorithmic_bytes_per_launch": frames_step * bytes_frame,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": bytes_frame},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.solver == "pg":
         line["cpu_baseline"] = cpu_baseline(fs, cfg, kp_host)
     if rank == 0:
         print(json.dumps(line))

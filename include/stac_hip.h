@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STAC_HIP_ABI_VERSION 1
+#define STAC_HIP_ABI_VERSION 2
 
 /* mjtJoint values (same as MuJoCo's, so tables from a MuJoCo compile can be passed as they are). */
 enum { STAC_JNT_FREE = 0, STAC_JNT_BALL = 1, STAC_JNT_SLIDE = 2, STAC_JNT_HINGE = 3 };
@@ -67,7 +67,15 @@ typedef struct stac_q_params {
     int32_t maxiter;         /* N_ITER_Q (>= 1) */
     int32_t maxls;           /* line-search halvings, jaxopt default 15 */
     int32_t lanes_per_chain; /* 0 = auto; else 4, 8, 16, 32 or 64 lanes of a wavefront per chain */
+    int32_t solver;          /* STAC_SOLVER_PG (the reference's algorithm, parity mode) or STAC_SOLVER_LM */
+    float lm_lambda0;        /* LM only: initial damping (0 -> 1e-2); maxiter then counts accepted LM steps */
 } stac_q_params;
+
+/* STAC_SOLVER_LM is an optional fast solver, NOT the reference's algorithm: projected Levenberg-Marquardt on the
+ * same objective, masks, bounds, stopping residual and sequencing (analytic site Jacobians, J^T J + damping,
+ * Cholesky in LDS).  It fits the markers at least as well as the truncated projected gradient but does not
+ * reproduce its iterates; it is available in stac_q_phase only. */
+enum { STAC_SOLVER_PG = 0, STAC_SOLVER_LM = 1 };
 
 typedef struct stac_model stac_model; /* opaque */
 

@@ -38,6 +38,10 @@ class OrcPgParams(C.Structure):
     _fields_ = [("tol", C.c_float), ("maxiter", C.c_int32), ("maxls", C.c_int32)]
 
 
+class OrcLmParams(C.Structure):
+    _fields_ = [("tol", C.c_float), ("maxiter", C.c_int32), ("lambda0", C.c_float)]
+
+
 class OrcPgState(C.Structure):
     _fields_ = [
         ("iter_num", C.c_int32), ("stepsize", C.c_float), ("error", C.c_float), ("t", C.c_float),
@@ -201,6 +205,41 @@ class Oracle:
             C.c_int32(root_dims), C.c_int32(1 if do_root_opt else 0), _p(qi, _f32p), _p(out["qpos"], _f32p),
             _p(out["xpos"], _f32p), _p(out["xquat"], _f32p), _p(out["marker_sites"], _f32p),
             _p(out["frame_error"], _f32p), _p(out["counters"], _u32p), C.c_int32(nthreads))  # fmt: skip
+        return out
+
+    # -- optional LM solver (not the reference's algorithm; see stac_oracle.h) -----------------------------------
+    def q_opt_lm(self, kp, qs_to_opt, kps_to_opt, q0, lb, ub, maxiter=40, lambda0=1e-2):
+        kp, q0, lb, ub = _f32(kp), _f32(q0), _f32(lb), _f32(ub)
+        qs, ks = _u8(qs_to_opt), _u8(kps_to_opt)
+        out = np.empty(self.nq, np.float32)
+        st = OrcPgState()
+        lp = OrcLmParams(self.params.tol, maxiter, lambda0)
+        self.lib.orc_q_opt_lm(C.byref(self.m), C.byref(lp), _p(kp, _f32p), _p(qs, _u8p), _p(ks, _u8p), _p(q0, _f32p),
+                              _p(lb, _f32p), _p(ub, _f32p), _p(out, _f32p), C.byref(st))
+        return out, st.as_dict()
+
+    def ik_clips_lm(self, kp, lb, ub, part_masks, trunk_kps, root_kp_idx, root_dims=7, do_root_opt=True, q_init=None,
+                    nthreads=0, want_bodies=True, maxiter=40, lambda0=1e-2):
+        kp, lb, ub = _f32(kp), _f32(lb), _f32(ub)
+        Cn, F = kp.shape[0], kp.shape[1]
+        pm = _u8(part_masks).reshape(-1, self.nq) if len(part_masks) else np.zeros((0, self.nq), np.uint8)
+        P = pm.shape[0]
+        tk = _u8(trunk_kps)
+        qi = _f32(q_init) if q_init is not None else None
+        lp = OrcLmParams(self.params.tol, maxiter, lambda0)
+        out = dict(
+            qpos=np.empty((Cn, F, self.nq), np.float32),
+            xpos=np.empty((Cn, F, self.nbody, 3), np.float32) if want_bodies else None,
+            xquat=np.empty((Cn, F, self.nbody, 4), np.float32) if want_bodies else None,
+            marker_sites=np.empty((Cn, F, self.K, 3), np.float32),
+            frame_error=np.empty((Cn, F), np.float32), counters=np.empty((Cn, F, 4), np.uint32),
+        )  # fmt: skip
+        self.lib.orc_ik_clips_lm(
+            C.byref(self.m), C.byref(lp), _p(kp, _f32p), C.c_int32(Cn), C.c_int32(F), _p(lb, _f32p), _p(ub, _f32p),
+            _p(pm, _u8p) if P else None, C.c_int32(P), _p(tk, _u8p), C.c_int32(root_kp_idx), C.c_int32(root_dims),
+            C.c_int32(1 if do_root_opt else 0), _p(qi, _f32p), _p(out["qpos"], _f32p), _p(out["xpos"], _f32p),
+            _p(out["xquat"], _f32p), _p(out["marker_sites"], _f32p), _p(out["frame_error"], _f32p),
+            _p(out["counters"], _u32p), C.c_int32(nthreads))  # fmt: skip
         return out
 
     def max_threads(self):

@@ -538,7 +538,224 @@ void orc_m_opt(const orc_model *m, const float *keypoints, const float *q, int32
     free(partial);
 }
 
+
+/* ============================================================================================================
+ * Optional fast solver: projected Levenberg-Marquardt (see stac_oracle.h).  NOT the reference's algorithm.
+ * ============================================================================================================ */
+typedef struct {
+    int nd;          /* optimised coordinates with structural support (ancestor of a fit site) */
+    int *dof;        /* [nd] qpos indices, increasing */
+    int *dof_jnt;    /* [nd] joint of each coordinate */
+    real *J;         /* [3K, nd] dx/dq */
+    real *A, *H;     /* [nd, nd] */
+    real *b, *d, *bb;/* [nd] */
+    unsigned char *frozen;
+} lm_ws_t;
+
+static lm_ws_t *lm_new(const orc_model *m) {
+    lm_ws_t *l = (lm_ws_t *)calloc(1, sizeof(lm_ws_t));
+    const int nq = m->nq, K = m->nsite;
+    l->dof = (int *)calloc(2 * (size_t)nq, sizeof(int));
+    l->dof_jnt = l->dof + nq;
+    l->J = (real *)calloc((size_t)3 * K * nq + 2 * (size_t)nq * nq + 3 * (size_t)nq, sizeof(real));
+    l->A = l->J + (size_t)3 * K * nq;
+    l->H = l->A + (size_t)nq * nq;
+    l->b = l->H + (size_t)nq * nq;
+    l->d = l->b + nq;
+    l->bb = l->d + nq;
+    l->frozen = (unsigned char *)calloc(nq, 1);
+    return l;
+}
+static void lm_free(lm_ws_t *l) {
+    if (l) { free(l->dof); free(l->J); free(l->frozen); free(l); }
+}
+
+/* Site Jacobian columns at the pose of the last fk_ws (w->qf normalised, anchors, axes, jnorm filled). */
+static void lm_jacobian(const orc_model *m, ws_t *w, lm_ws_t *l) {
+    const int K = m->nsite, nd = l->nd;
+    for (size_t i = 0; i < (size_t)3 * K * nd; ++i) l->J[i] = R(0);
+    for (int c = 0; c < nd; ++c) {
+        const int j = l->dof_jnt[c], b = m->jnt_bodyid[j], a = m->jnt_qposadr[j], comp = l->dof[c] - a;
+        const real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
+        for (int i = w->blo[b]; i < w->bhi[b]; ++i) { /* sites of the joint's body subtree */
+            const int k = w->sord[i];
+            real dvec[3], col[3];
+            for (int t = 0; t < 3; ++t) dvec[t] = w->sx[3 * k + t] - anchor[t];
+            switch (m->jnt_type[j]) {
+            case ORC_JNT_HINGE: cross3(axis, dvec, col); break;
+            case ORC_JNT_SLIDE: col[0] = axis[0]; col[1] = axis[1]; col[2] = axis[2]; break;
+            case ORC_JNT_FREE:
+                if (comp < 3) { col[0] = comp == 0; col[1] = comp == 1; col[2] = comp == 2; }
+                else {
+                    /* raw quaternion (s,u), q^ = q/|q|: dx/ds = -2 (u^ x d)/|q|, dx/du_j = 2 (s^ (e_j x d) - (e_j x u^) x d)/|q| */
+                    const real *qh = w->qf + a + 3;
+                    const real n = w->jnorm[j], dn = n + (n == R(0) ? R(1e-6) : R(0));
+                    if (comp == 3) {
+                        cross3(qh + 1, dvec, col);
+                        for (int t = 0; t < 3; ++t) col[t] = (R(-2) * col[t]) / dn;
+                    } else {
+                        real e[3] = {R(0), R(0), R(0)}, exd[3], exu[3], t2[3];
+                        e[comp - 4] = R(1);
+                        cross3(e, dvec, exd);
+                        cross3(e, qh + 1, exu);
+                        cross3(exu, dvec, t2);
+                        for (int t = 0; t < 3; ++t) col[t] = (R(2) * (qh[0] * exd[t] - t2[t])) / dn;
+                    }
+                }
+                break;
+            default: col[0] = col[1] = col[2] = R(0); break; /* ball: unsupported */
+            }
+            for (int t = 0; t < 3; ++t) l->J[(size_t)(3 * k + t) * nd + c] = col[t];
+        }
+    }
+}
+
+/* In-place dense Cholesky solve of the SPD system H d = bb (nd x nd, row-major, lower triangle used). */
+static int lm_chol_solve(int n, real *H, const real *bb, real *d) {
+    for (int j = 0; j < n; ++j) {
+        real s = H[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) s -= H[(size_t)j * n + k] * H[(size_t)j * n + k];
+        if (!(s > R(0))) return -1;
+        const real ljj = rsqrt_(s);
+        H[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            real t = H[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) t -= H[(size_t)i * n + k] * H[(size_t)j * n + k];
+            H[(size_t)i * n + j] = t / ljj;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        real t = bb[i];
+        for (int k = 0; k < i; ++k) t -= H[(size_t)i * n + k] * d[k];
+        d[i] = t / H[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        real t = d[i];
+        for (int k = i + 1; k < n; ++k) t -= H[(size_t)k * n + i] * d[k];
+        d[i] = t / H[(size_t)i * n + i];
+    }
+    return 0;
+}
+
+static void q_opt_lm_ws(const orc_model *m, ws_t *w, lm_ws_t *l, const orc_lm_params *p, const uint8_t *qs_to_opt,
+                        const uint8_t *kps_to_opt, orc_pg_state *st) {
+    /* inputs in w->q0 (start AND initial_q), w->kp, w->lb, w->ub; result in w->x */
+    const int nq = m->nq, K = m->nsite;
+    real *x = w->x, *xt = w->cand, *g = w->g;
+    for (int i = 0; i < nq; ++i) x[i] = w->q0[i];
+    /* coordinates: optimised AND on the root path of some fit site */
+    l->nd = 0;
+    for (int j = 0; j < m->njnt; ++j) {
+        const int b = m->jnt_bodyid[j], a = m->jnt_qposadr[j];
+        const int dims = m->jnt_type[j] == ORC_JNT_FREE ? 7 : (m->jnt_type[j] == ORC_JNT_BALL ? 4 : 1);
+        if (w->bhi[b] <= w->blo[b] || m->jnt_type[j] == ORC_JNT_BALL) continue;
+        for (int c = 0; c < dims; ++c)
+            if (qs_to_opt[a + c]) { l->dof[l->nd] = a + c; l->dof_jnt[l->nd] = j; l->nd++; }
+    }
+    const int nd = l->nd;
+    real lam = R(p->lambda0);
+    int iter = 0, evals = 0, gevals = 0;
+    real f = q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, g);
+    ++gevals;
+    real error = (real)INFINITY;
+    for (;;) {
+        /* stopping residual, same definition as the PG solver */
+        for (int i = 0; i < nq; ++i) { const real dd = clipr(x[i] - g[i], w->lb[i], w->ub[i]) - x[i]; w->tb0[i] = dd * dd; }
+        error = rsqrt_(tree_sum(w->tb0, nq));
+        if (!(error > R(p->tol)) || iter >= p->maxiter || nd == 0) break;
+        /* Gauss-Newton system at x (fk_ws state is that of x: the last q_loss_ws call evaluated x) */
+        lm_jacobian(m, w, l);
+        for (int a = 0; a < nd; ++a) {
+            for (int b2 = 0; b2 <= a; ++b2) {
+                real s = R(0);
+                for (int r = 0; r < 3 * K; ++r)
+                    if (kps_to_opt[r]) s += l->J[(size_t)r * nd + a] * l->J[(size_t)r * nd + b2];
+                l->A[(size_t)a * nd + b2] = s;
+                l->A[(size_t)b2 * nd + a] = s;
+            }
+            l->b[a] = R(-0.5) * g[l->dof[a]];
+        }
+        /* gauge of the raw root quaternion: its length does not change the pose; make that direction stiff */
+        for (int j = 0; j < m->njnt; ++j) {
+            if (m->jnt_type[j] != ORC_JNT_FREE) continue;
+            int idx[4], have = 1;
+            for (int c = 0; c < 4; ++c) {
+                idx[c] = -1;
+                for (int a = 0; a < nd; ++a) if (l->dof[a] == m->jnt_qposadr[j] + 3 + c) idx[c] = a;
+                if (idx[c] < 0) have = 0;
+            }
+            if (!have) continue;
+            const real *qh = w->qf + m->jnt_qposadr[j] + 3;
+            for (int c = 0; c < 4; ++c) for (int e = 0; e < 4; ++e) l->A[(size_t)idx[c] * nd + idx[e]] += qh[c] * qh[e];
+        }
+        for (int a = 0; a < nd; ++a) {
+            const int i = l->dof[a];
+            l->frozen[a] = (x[i] <= w->lb[i] && l->b[a] < R(0)) || (x[i] >= w->ub[i] && l->b[a] > R(0));
+        }
+        int accepted = 0;
+        for (int tries = 0; tries < 8 && !accepted; ++tries) {
+            for (int a = 0; a < nd; ++a) {
+                for (int b2 = 0; b2 < nd; ++b2)
+                    l->H[(size_t)a * nd + b2] = (l->frozen[a] || l->frozen[b2]) ? R(0) : l->A[(size_t)a * nd + b2];
+                l->H[(size_t)a * nd + a] = l->frozen[a] ? R(1) : l->A[(size_t)a * nd + a] * (R(1) + lam) + R(1e-9);
+                l->bb[a] = l->frozen[a] ? R(0) : l->b[a];
+            }
+            if (lm_chol_solve(nd, l->H, l->bb, l->d) != 0) { lam = lam * R(4); continue; }
+            for (int i = 0; i < nq; ++i) xt[i] = x[i];
+            for (int a = 0; a < nd; ++a) { const int i = l->dof[a]; xt[i] = clipr(x[i] + l->d[a], w->lb[i], w->ub[i]); }
+            const real ft = q_loss_ws(m, w, xt, w->kp, qs_to_opt, kps_to_opt, w->q0, w->gn);
+            ++evals; ++gevals;
+            if (ft < f) {
+                for (int i = 0; i < nq; ++i) { x[i] = xt[i]; g[i] = w->gn[i]; }
+                f = ft;
+                lam = lam * R(0.5);
+                if (lam < R(1e-9)) lam = R(1e-9);
+                accepted = 1;
+            } else {
+                lam = lam * R(4);
+            }
+        }
+        if (!accepted) {
+            /* no decrease found: restore the fk_ws state of x for the caller and stop */
+            (void)q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, g);
+            break;
+        }
+        ++iter;
+    }
+    if (st) {
+        st->iter_num = iter;
+        st->stepsize = (float)lam;
+        st->error = (float)error;
+        st->t = R(0);
+        st->ls_evals = evals;
+        st->grad_evals = gevals;
+        st->loss = (float)f;
+    }
+}
+
+void orc_q_opt_lm(const orc_model *m, const orc_lm_params *p, const float *kp, const uint8_t *qs_to_opt,
+                  const uint8_t *kps_to_opt, const float *q0, const float *lb, const float *ub,
+                  float *params_out, orc_pg_state *state_out) {
+    ws_t *w = ws_new(m);
+    lm_ws_t *l = lm_new(m);
+    ws_set_bounds(m, w, lb, ub);
+    for (int i = 0; i < m->nq; ++i) w->q0[i] = R(q0[i]);
+    for (int i = 0; i < 3 * m->nsite; ++i) w->kp[i] = R(kp[i]);
+    q_opt_lm_ws(m, w, l, p, qs_to_opt, kps_to_opt, state_out);
+    for (int i = 0; i < m->nq; ++i) params_out[i] = (float)w->x[i];
+    lm_free(l);
+    ws_free(w);
+}
+
 /* ---- phase drivers (compute_stac.py) -------------------------------------------------------- */
+/* `lm` != NULL swaps every PG solve for the LM solver (orc_ik_clips_lm); sequencing is unchanged. */
+typedef struct { const orc_lm_params *p; lm_ws_t *l; } lm_opt_t;
+static void solve_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const lm_opt_t *lm, const uint8_t *qs,
+                     const uint8_t *ks, orc_pg_state *st) {
+    if (lm && lm->p) q_opt_lm_ws(m, w, lm->l, lm->p, qs, ks, st);
+    else q_opt_ws(m, w, p, qs, ks, st);
+}
+
 /* utils.replace_qs: qpos <- make_qs(q0, mask, params); kinematics (normalises quaternions). */
 static void replace_qs_ws(const orc_model *m, ws_t *w, const uint8_t *mask, real *qpos) {
     for (int i = 0; i < m->nq; ++i) {
@@ -548,7 +765,7 @@ static void replace_qs_ws(const orc_model *m, ws_t *w, const uint8_t *mask, real
     fk_ws(m, w, qpos);
 }
 
-static void root_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const float *kp_clip,
+static void root_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const lm_opt_t *lm, const float *kp_clip,
                         int frame, int root_kp_idx, int root_dims, const uint8_t *trunk_kps,
                         real *qpos, orc_pg_state *st) {
     const int nq = m->nq, K = m->nsite;
@@ -560,7 +777,7 @@ static void root_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, con
     for (int pass = 0; pass < 2; ++pass) { /* compute_stac.py:57-98: two identical solves */
         for (int i = 0; i < nq; ++i) w->q0[i] = qpos[i];
         for (int i = 0; i < 3; ++i) w->q0[i] = R(kpf[3 * root_kp_idx + i]);
-        q_opt_ws(m, w, p, qs, kps, st);
+        solve_ws(m, w, p, lm, qs, kps, st);
         replace_qs_ws(m, w, qs, qpos);
     }
     free(qs); free(kps);
@@ -574,13 +791,13 @@ void orc_root_optimization(const orc_model *m, const orc_pg_params *p, const flo
     ws_set_bounds(m, w, lb, ub);
     real *qp = (real *)malloc(sizeof(real) * m->nq);
     for (int i = 0; i < m->nq; ++i) qp[i] = R(qpos[i]);
-    root_opt_ws(m, w, p, kp_clip, frame, root_kp_idx, root_dims, trunk_kps, qp, last_state);
+    root_opt_ws(m, w, p, NULL, kp_clip, frame, root_kp_idx, root_dims, trunk_kps, qp, last_state);
     for (int i = 0; i < m->nq; ++i) qpos[i] = (float)qp[i];
     free(qp);
     ws_free(w);
 }
 
-static void pose_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const float *kp_clip,
+static void pose_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, const lm_opt_t *lm, const float *kp_clip,
                         int F, const uint8_t *part_masks, int P, real *qpos, float *qposes,
                         float *xposes, float *xquats, float *markers, float *frame_error,
                         uint32_t *counters) {
@@ -595,14 +812,14 @@ static void pose_opt_ws(const orc_model *m, ws_t *w, const orc_pg_params *p, con
         for (int i = 0; i < 3 * K; ++i) w->kp[i] = R(kpf[i]);
         /* full-body solve (compute_stac.py:217-231) */
         for (int i = 0; i < nq; ++i) w->q0[i] = qpos[i];
-        q_opt_ws(m, w, p, all_q, all_k, &st);
+        solve_ws(m, w, p, lm, all_q, all_k, &st);
         cnt[0] += st.iter_num; cnt[1] += st.ls_evals; cnt[2] += st.grad_evals; cnt[3] += 1;
         replace_qs_ws(m, w, NULL, qpos);
         /* individual part solves (compute_stac.py:233-250) */
         for (int pi = 0; pi < P; ++pi) {
             const uint8_t *mask = part_masks + (size_t)pi * nq;
             for (int i = 0; i < nq; ++i) w->q0[i] = qpos[i];
-            q_opt_ws(m, w, p, mask, all_k, &st);
+            solve_ws(m, w, p, lm, mask, all_k, &st);
             cnt[0] += st.iter_num; cnt[1] += st.ls_evals; cnt[2] += st.grad_evals; cnt[3] += 1;
             replace_qs_ws(m, w, mask, qpos);
         }
@@ -625,7 +842,7 @@ void orc_pose_optimization(const orc_model *m, const orc_pg_params *p, const flo
     ws_set_bounds(m, w, lb, ub);
     real *qp = (real *)malloc(sizeof(real) * m->nq);
     for (int i = 0; i < m->nq; ++i) qp[i] = R(qpos[i]);
-    pose_opt_ws(m, w, p, kp_clip, F, part_masks, P, qp, qposes, xposes, xquats, markers, frame_error, counters);
+    pose_opt_ws(m, w, p, NULL, kp_clip, F, part_masks, P, qp, qposes, xposes, xquats, markers, frame_error, counters);
     for (int i = 0; i < m->nq; ++i) qpos[i] = (float)qp[i];
     free(qp);
     ws_free(w);
@@ -639,7 +856,7 @@ int32_t orc_max_threads(void) {
 #endif
 }
 
-void orc_ik_clips(const orc_model *m, const orc_pg_params *p, const float *kp, int32_t C,
+static void ik_clips_impl(const orc_model *m, const orc_pg_params *p, const orc_lm_params *lmp, const float *kp, int32_t C,
                   int32_t F, const float *lb, const float *ub, const uint8_t *part_masks,
                   int32_t P, const uint8_t *trunk_kps, int32_t root_kp_idx, int32_t root_dims,
                   int32_t do_root_opt, const float *q_init, float *qposes, float *xposes,
@@ -656,14 +873,16 @@ void orc_ik_clips(const orc_model *m, const orc_pg_params *p, const float *kp, i
         ws_t *w = ws_new(m);
         ws_set_bounds(m, w, lb, ub);
         real *qp = (real *)malloc(sizeof(real) * nq);
+        lm_opt_t lmo = {lmp, lmp ? lm_new(m) : NULL};
+        const lm_opt_t *lm = lmp ? &lmo : NULL;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic)
 #endif
         for (int c = 0; c < C; ++c) {
             for (int i = 0; i < nq; ++i) qp[i] = q_init ? R(q_init[(size_t)c * nq + i]) : w->qpos0[i];
             const float *kpc = kp + (size_t)c * F * 3 * K;
-            if (do_root_opt) root_opt_ws(m, w, p, kpc, 0, root_kp_idx, root_dims, trunk_kps, qp, NULL);
-            pose_opt_ws(m, w, p, kpc, F, part_masks, P, qp,
+            if (do_root_opt) root_opt_ws(m, w, p, lm, kpc, 0, root_kp_idx, root_dims, trunk_kps, qp, NULL);
+            pose_opt_ws(m, w, p, lm, kpc, F, part_masks, P, qp,
                         qposes ? qposes + (size_t)c * F * nq : NULL,
                         xposes ? xposes + (size_t)c * F * nb * 3 : NULL,
                         xquats ? xquats + (size_t)c * F * nb * 4 : NULL,
@@ -672,7 +891,27 @@ void orc_ik_clips(const orc_model *m, const orc_pg_params *p, const float *kp, i
                         counters ? counters + (size_t)c * F * 4 : NULL);
         }
         free(qp);
+        lm_free(lmo.l);
         ws_free(w);
     }
     (void)nthreads;
+}
+
+void orc_ik_clips(const orc_model *m, const orc_pg_params *p, const float *kp, int32_t C,
+                  int32_t F, const float *lb, const float *ub, const uint8_t *part_masks,
+                  int32_t P, const uint8_t *trunk_kps, int32_t root_kp_idx, int32_t root_dims,
+                  int32_t do_root_opt, const float *q_init, float *qposes, float *xposes,
+                  float *xquats, float *markers, float *frame_error, uint32_t *counters,
+                  int32_t nthreads) {
+    ik_clips_impl(m, p, NULL, kp, C, F, lb, ub, part_masks, P, trunk_kps, root_kp_idx, root_dims, do_root_opt, q_init,
+                  qposes, xposes, xquats, markers, frame_error, counters, nthreads);
+}
+
+void orc_ik_clips_lm(const orc_model *m, const orc_lm_params *p, const float *kp, int32_t C, int32_t F,
+                     const float *lb, const float *ub, const uint8_t *part_masks, int32_t P,
+                     const uint8_t *trunk_kps, int32_t root_kp_idx, int32_t root_dims, int32_t do_root_opt,
+                     const float *q_init, float *qposes, float *xposes, float *xquats, float *markers,
+                     float *frame_error, uint32_t *counters, int32_t nthreads) {
+    ik_clips_impl(m, NULL, p, kp, C, F, lb, ub, part_masks, P, trunk_kps, root_kp_idx, root_dims, do_root_opt, q_init,
+                  qposes, xposes, xquats, markers, frame_error, counters, nthreads);
 }

@@ -90,6 +90,31 @@ void orc_q_opt(const orc_model *m, const orc_pg_params *p, const float *kp,
                const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const float *q0,
                const float *lb, const float *ub, float *params_out, orc_pg_state *state_out);
 
+/* ---- optional fast solver (NOT the reference's algorithm) --------------------------------------------------
+ * Projected Levenberg-Marquardt on the same objective, bounds and masks as orc_q_opt (the "LM qpos update" of
+ * BASELINE.json's north star).  It does not reproduce the reference's truncated
+ * projected-gradient iterates and is judged in marker space.  Per iteration: Gauss-Newton matrix A = J^T W J and
+ * b = J^T W (kp - x) from analytic site Jacobians, multiplicative damping A_ii (1 + lambda) + mu, bound-active
+ * coordinates frozen, dense Cholesky, step clipped to the box, accepted if the loss decreases (lambda /= 2) else
+ * lambda *= 4 (at most 8 times in a row).  Stops on the same residual as the PG solver (||clip(x - grad) - x|| <= tol) or after maxiter
+ * accepted steps.  Ball joints are not supported. */
+typedef struct {
+    float tol;       /* same stopping residual as the PG solver */
+    int32_t maxiter; /* accepted steps, e.g. 40 */
+    float lambda0;   /* initial damping, e.g. 1e-2 */
+} orc_lm_params;
+
+void orc_q_opt_lm(const orc_model *m, const orc_lm_params *p, const float *kp, const uint8_t *qs_to_opt,
+                  const uint8_t *kps_to_opt, const float *q0, const float *lb, const float *ub,
+                  float *params_out, orc_pg_state *state_out);
+
+/* orc_ik_clips with the LM solver in place of every PG solve (same sequencing, masks and replace_qs). */
+void orc_ik_clips_lm(const orc_model *m, const orc_lm_params *p, const float *kp, int32_t C, int32_t F,
+                     const float *lb, const float *ub, const uint8_t *part_masks, int32_t P,
+                     const uint8_t *trunk_kps, int32_t root_kp_idx, int32_t root_dims, int32_t do_root_opt,
+                     const float *q_init, float *qposes, float *xposes, float *xquats, float *markers,
+                     float *frame_error, uint32_t *counters, int32_t nthreads);
+
 /* Cross-frame partial sums of the offset phase: partial[3K+2] = {s[K,3], z2, T}. */
 void orc_m_partial(const orc_model *m, const float *keypoints, const float *q, int32_t T,
                    float *partial);

@@ -18,6 +18,8 @@
 namespace stac {
 hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
                           int *capacity_out);
+hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
+                             int *capacity_out);
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s);
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
@@ -53,6 +55,12 @@ struct stac_model {
     float *d_site_pos = nullptr;  // [K,3] offsets for the stand-alone FK / m-phase kernels (mirrors the plan's SiteRec.pos)
     uint8_t *d_masks = nullptr;  // [kMaxKinds, nqpad] + [K] + [3K]
     std::vector<uint8_t> masks_cache;  // what d_masks currently holds (uploads + their sync happen only on change)
+    // host copies of the plan's structure, used to build the LM solver's per-kind tables
+    std::vector<int> h_ab_parent, h_aj_type, h_aj_qadr, h_aj_slot, h_aj_slo, h_aj_shi, h_sortpos;
+    int32_t *d_lm_tab = nullptr;
+    size_t lm_tab_words = 0;
+    std::vector<int32_t> lm_tab_cache;
+    LmArgs lm_args{};
     size_t masks_bytes = 0;
     float *d_scratch = nullptr;  // grown on demand (xpos/xquat when the caller does not want them)
     size_t scratch_floats = 0;
@@ -179,6 +187,8 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.nqpad = (nq + 3) & ~3;
     h.has_ball = has_ball;
     m->max_depth = nlev;
+    m->h_ab_parent = ab_parent; m->h_aj_type = aj_type; m->h_aj_qadr = aj_qadr; m->h_aj_slot = aj_slot;
+    m->h_aj_slo = aj_slo; m->h_aj_shi = aj_shi; m->h_sortpos = sortpos;
     if (nab >= 65535 || K >= 65535) return fail(STAC_ERR_CAPACITY, "too many bodies / sites");
 
     std::vector<float> &B = m->blob_host;
@@ -332,7 +342,7 @@ extern "C" void stac_model_destroy(stac_model *m) {
     if (!m) return;
     void *ptrs[] = {m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
                     m->d_body_quat, m->d_jnt_type, m->d_jnt_qposadr, m->d_jnt_pos, m->d_jnt_axis,
-                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch};
+                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -471,6 +481,142 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     return STAC_OK;
 }
 
+
+// ---- LM solver: per-kind tables (dofs, non-zero J^T J entries, (site, dof) Jacobian items) ------------------------
+static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]*/, int nkinds, float lambda0, hipStream_t s) {
+    const PlanHeader &h = m->h;
+    const int naj = h.naj, nab = h.nab;
+    if (h.has_ball) return fail(STAC_ERR_INVALID, "STAC_SOLVER_LM does not support ball joints");
+    std::vector<int32_t> tab((size_t)nkinds * 8, 0);
+    int n_max = 0, maxpd_all = 1;
+    auto is_anc_or_self = [&](int sa, int sb) {  // slot sa ancestor-or-equal of slot sb
+        for (int s2 = sb; s2 >= 0; s2 = m->h_ab_parent[s2] - 1) if (s2 == sa) return true;
+        return false;
+    };
+    for (int kind = 0; kind < nkinds; ++kind) {
+        const uint8_t *mask = masks + (size_t)kind * h.nqpad;
+        struct Dof { int qadr, joint, comp, pd; };
+        std::vector<Dof> D;
+        for (int j = 0; j < naj; ++j) {
+            if (m->h_aj_shi[j] <= m->h_aj_slo[j]) continue;  // no fit site below this joint
+            const int dims = m->h_aj_type[j] == STAC_JNT_FREE ? 7 : 1;
+            for (int c = 0; c < dims; ++c)
+                if (mask[m->h_aj_qadr[j] + c]) D.push_back({m->h_aj_qadr[j] + c, j, c, 0});
+        }
+        const int nd = (int)D.size();
+        std::vector<int32_t> ents, items;
+        int maxpd = 1;
+        struct Ent { int row, col, pds, range, len; };
+        std::vector<Ent> E;
+        for (int b = 0; b < nd; ++b) {
+            const int jb = D[b].joint, sb = m->h_aj_slot[jb];
+            int pd = 0;
+            std::vector<int> path;
+            for (int a2 = 0; a2 <= b; ++a2)
+                if (a2 == b || is_anc_or_self(m->h_aj_slot[D[a2].joint], sb)) path.push_back(a2);
+            pd = (int)path.size() - 1;
+            D[b].pd = pd;
+            maxpd = std::max(maxpd, pd + 1);
+            const int lo = m->h_aj_slo[jb], hi = m->h_aj_shi[jb];
+            for (int pi = 0; pi < (int)path.size(); ++pi)
+                E.push_back({b, path[pi], pd | (pi << 8), lo | (hi << 16), hi - lo});
+            for (int i = lo; i < hi; ++i) { items.push_back(i); items.push_back(b); items.push_back(pd); items.push_back(0); }
+        }
+        if (maxpd > 255) return fail(STAC_ERR_CAPACITY, "kinematic path too deep for the LM solver");
+        std::stable_sort(E.begin(), E.end(), [](const Ent &x, const Ent &y) { return x.len > y.len; });
+        for (const Ent &e : E) { ents.push_back(e.row); ents.push_back(e.col); ents.push_back(e.pds); ents.push_back(e.range); }
+        int quat0 = -1;
+        for (int b = 0; b + 3 < nd; ++b)
+            if (m->h_aj_type[D[b].joint] == STAC_JNT_FREE && D[b].comp == 3 && D[b + 3].joint == D[b].joint && D[b + 3].comp == 6)
+                quat0 = b;
+        int32_t *kh = tab.data() + (size_t)kind * 8;
+        kh[0] = nd; kh[1] = (int)E.size(); kh[2] = (int)items.size() / 4; kh[3] = maxpd;
+        kh[4] = (int)tab.size();
+        for (const Dof &d : D) { tab.push_back(d.qadr); tab.push_back(d.joint); tab.push_back(d.comp); tab.push_back(d.pd); }
+        kh = tab.data() + (size_t)kind * 8;
+        kh[5] = (int)tab.size();
+        tab.insert(tab.end(), ents.begin(), ents.end());
+        kh = tab.data() + (size_t)kind * 8;
+        kh[6] = (int)tab.size();
+        tab.insert(tab.end(), items.begin(), items.end());
+        kh = tab.data() + (size_t)kind * 8;
+        kh[7] = quat0;
+        n_max = std::max(n_max, nd);
+        maxpd_all = std::max(maxpd_all, maxpd);
+    }
+    (void)nab;
+    if (tab != m->lm_tab_cache) {
+        if (tab.size() > m->lm_tab_words) {
+            if (m->d_lm_tab) (void)hipFree(m->d_lm_tab);
+            m->d_lm_tab = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_lm_tab), tab.size() * sizeof(int32_t)));
+            m->lm_tab_words = tab.size();
+        }
+        HIP_TRY(hipMemcpyAsync(m->d_lm_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        m->lm_tab_cache = tab;
+    }
+    LmArgs &L = m->lm_args;
+    L.tab = m->d_lm_tab;
+    L.nkinds = nkinds;
+    L.n_max = std::max(n_max, 1);
+    L.npk = ((L.n_max * (L.n_max + 1)) / 2 + 3) & ~3;
+    L.maxpd = maxpd_all;
+    L.lambda0 = lambda0 > 0.0f ? lambda0 : 1e-2f;
+    int o = h.chain_stride;
+    o = (o + 3) & ~3;
+    L.c_sx = o; o += 3 * h.K;
+    o = (o + 3) & ~3;
+    L.c_jp = o; o += std::max(h.K * L.maxpd * 3, L.npk);
+    o = (o + 3) & ~3;
+    L.c_A = o; o += L.npk;
+    L.c_b = o; o += L.n_max;
+    L.c_d = o; o += L.n_max;
+    L.c_fz = o; o += L.n_max;
+    if ((o & 1) == 0) o += 1;
+    L.chain_stride = o;
+    return STAC_OK;
+}
+
+static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains, const uint8_t *host_masks, hipStream_t s) {
+    if (p->maxiter < 1) return fail(STAC_ERR_INVALID, "maxiter must be >= 1");
+    const int nkinds = a.P + 3;
+    const int rc = build_lm_tables(m, host_masks, nkinds, p->lm_lambda0, s);
+    if (rc != STAC_OK) return rc;
+    a.hdr = nullptr;
+    a.plan = m->d_blob;
+    a.h = m->h;
+    a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
+    const LmArgs &L = m->lm_args;
+    int G = (p->lanes_per_chain == 16 || p->lanes_per_chain == 32 || p->lanes_per_chain == 64) ? p->lanes_per_chain
+            : (nchains >= 1024 ? 16 : 64);
+    hipError_t e = hipErrorInvalidValue;
+    int cap = 0;
+    for (; !cap && G <= 64; G *= 2) {
+        const int cpw = 64 / G;
+        const int mbw = (2 * nkinds * G + 3) & ~3, khw = (nkinds * 8 + 3) & ~3;
+        auto lds_for = [&](int wpb) { return (size_t)(((m->h.total_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
+        int wpb = 0, best_waves = 0;
+        for (int w = 1; w <= 4; ++w) {
+            size_t lds = lds_for(w);
+            if (lds > kLdsPerCu) break;
+            lds = (lds + 1279) / 1280 * 1280;
+            int blocks = (int)(kLdsPerCu / lds);
+            if (blocks * w > 8) blocks = 8 / w;
+            if (blocks * w > best_waves) { best_waves = blocks * w; wpb = w; }
+        }
+        if (!wpb) continue;
+        a.mb_words = mbw;
+        if (getenv("STAC_HIP_VERBOSE"))
+            fprintf(stderr, "[stac] q_phase LM: chains=%d G=%d wpb=%d waves/CU=%d lds=%zu B/block chain_stride=%d n_max=%d maxpd=%d\n",
+                    nchains, G, wpb, best_waves, lds_for(wpb), L.chain_stride, L.n_max, L.maxpd);
+        e = launch_q_phase_lm(a, L, G, wpb, lds_for(wpb), s, &cap);
+    }
+    if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the LM q_phase kernel limits (LDS per CU / nq)");
+    if (e != hipSuccess) return fail(STAC_ERR_HIP, std::string("q_phase LM launch: ") + hipGetErrorString(e));
+    return STAC_OK;
+}
+
 extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, const float *kp, const float *q0,
                                 const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, int32_t N,
                                 float *params_out, float *state_out, uint32_t *counters_out, void *stream) {
@@ -478,6 +624,7 @@ extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, co
     if (!m || !p || !kp || !q0 || !qs_to_opt || !kps_to_opt || !params_out || !state_out || N < 0)
         return fail(STAC_ERR_INVALID, "stac_q_solve: bad argument");
     if (N == 0) return STAC_OK;
+    if (p->solver != STAC_SOLVER_PG) return fail(STAC_ERR_INVALID, "stac_q_solve implements the reference's projected gradient only");
     hipStream_t s = (hipStream_t)stream;
     const int nqpad = m->h.nqpad, K = m->h.K, nq = m->h.nq;
     std::vector<uint8_t> hostm((size_t)nqpad + 3 * K + 1, 0);
@@ -522,10 +669,12 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     for (int pi = 0; pi < P; ++pi) std::memcpy(hostm.data() + (size_t)(3 + pi) * nqpad, part_masks + (size_t)pi * nq, nq);
     uint8_t *d_kpw = m->d_masks + (size_t)kMaxKinds * nqpad;
     for (int k = 0; k < K; ++k) hostm[(size_t)(P + 3) * nqpad + k] = (trunk_kps && trunk_kps[k]) ? 1 : 0;
+    for (int k = 0; k < K; ++k) hostm.push_back((trunk_kps && trunk_kps[k]) ? 1 : 0);  // placeholder, reordered below
+    for (int k = 0; k < K; ++k) hostm[(size_t)(P + 3) * nqpad + K + m->h_sortpos[k]] = (trunk_kps && trunk_kps[k]) ? 1 : 0;
     hostm.push_back(0x5A);  // tag: phase layout
     if (hostm != m->masks_cache) {
         HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), (size_t)(P + 3) * nqpad, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_kpw, hostm.data() + (size_t)(P + 3) * nqpad, K, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_kpw, hostm.data() + (size_t)(P + 3) * nqpad, 2 * K, hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
         m->masks_cache = hostm;
     }
@@ -533,7 +682,8 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.kp = kp; a.q_init = q_init; a.masks = m->d_masks; a.kpw = d_kpw; a.kpw3 = nullptr;
     a.C = C; a.F = F; a.P = P; a.root_kp_idx = root_kp_idx; a.do_root_opt = do_root_opt ? 1 : 0; a.single = 0;
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;
-    const int rc = run_q(m, p, a, C, s);
+    a.kpw_sorted = d_kpw + K;
+    const int rc = p->solver == STAC_SOLVER_LM ? run_q_lm(m, p, a, C, hostm.data(), s) : run_q(m, p, a, C, s);
     if (rc != STAC_OK) return rc;
     if (xpos_out || xquat_out || markers_out)
         // qpos_out already holds kinematics' normalised quaternions: use them as they are

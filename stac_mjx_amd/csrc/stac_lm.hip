@@ -1,0 +1,530 @@
+// stac_lm.hip -- optional fast q_phase solver: projected Levenberg-Marquardt (STAC_SOLVER_LM).
+//
+// NOT the reference's algorithm (the reference runs jaxopt.ProjectedGradient, stac_mjx/stac_core.py:182-191,
+// which stac_kernels.hip reproduces bit for bit).  This is the "LM qpos update" of BASELINE.json's north star
+// (SURVEY.md section 7 step 6): same objective, masks, bounds, stopping residual and phase sequencing
+// (compute_stac.py:17-104,170-278), judged in marker space.  oracle/stac_oracle.c::q_opt_lm_ws is its CPU
+// statement; tests compare the two with tolerances (LM iterates are not reproduced bit for bit).
+//
+// Mapping: like the PG kernel a wavefront is split into groups of G lanes, one chain per group, every trip
+// round the main loop evaluates one point per group (FK over the marker-ancestor subtree, site residuals,
+// analytic gradient).  An accepted point additionally gets its Gauss-Newton system: weighted site Jacobian
+// blocks J[site][dof on its root path] in LDS, the structurally non-zero entries of J^T W J summed by one lane
+// per entry over a contiguous range of DFS-ordered sites, damping A_ii (1 + lambda) + mu, coordinates at an
+// active bound frozen, dense packed Cholesky + substitutions in LDS, step clipped to the box.
+#include <hip/hip_runtime.h>
+
+#include "stac_device.hpp"
+#include "stac_plan.hpp"
+
+namespace stac {
+
+enum : int { LM_EVAL_X = 0, LM_TRIAL = 1, LM_DONE = 3 };
+
+__device__ __forceinline__ int pk(int i, int j) { return (i * (i + 1)) / 2 + j; }  // packed lower triangle, j <= i
+
+template <int G, int NQR>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
+    extern __shared__ float lds[];
+    constexpr int CPW = 64 / G;
+    const PlanHeader &H = a.h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int grp = lane / G, lg = lane % G;
+    const int nq = H.nq, K = H.K, nqpad = H.nqpad;
+
+    // ---- plan, mask bits, LM kind headers into LDS ----------------------------------------------------------
+    float *P = lds;
+    for (int i = threadIdx.x; i < H.total_words; i += blockDim.x) P[i] = a.plan[i];
+    const int plan_words = (H.total_words + 3) & ~3;
+    uint32_t *MB = reinterpret_cast<uint32_t *>(lds + plan_words);  // [2][nkinds][G]: qs_to_opt bits, dof bits
+    const int nkinds = a.P + 3;
+    int *KH = reinterpret_cast<int *>(lds + plan_words + a.mb_words);  // LmKind[nkinds]
+    for (int i = threadIdx.x; i < nkinds * 8; i += blockDim.x) KH[i] = L.tab[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nkinds * G; i += blockDim.x) {
+        const int kind = i / G, l = i % G;
+        uint32_t bits = 0, dbits = 0;
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + l;
+            if (e < nq && a.masks[kind * nqpad + e]) bits |= (1u << r);
+        }
+        const LmKind *kh = reinterpret_cast<const LmKind *>(KH + 8 * kind);
+        for (int d = 0; d < kh->nd; ++d) {
+            const int e = L.tab[kh->off_dof + 4 * d];
+            if (e % G == l) dbits |= (1u << (e / G));
+        }
+        MB[i] = bits;
+        MB[nkinds * G + i] = dbits;
+    }
+    const int kh_words = (nkinds * 8 + 3) & ~3;
+    float *CB = lds + plan_words + a.mb_words + kh_words + (wave * CPW + grp) * L.chain_stride;
+    float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn;
+    float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
+    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
+    float *sxs = CB + L.c_sx, *Jp = CB + L.c_jp, *Hc = CB + L.c_jp, *Ap = CB + L.c_A;
+    float *bv = CB + L.c_b, *dv = CB + L.c_d, *fz = CB + L.c_fz;
+    __syncthreads();
+
+    const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
+    const float *brec = P + H.off_body, *jrec = P + H.off_joint, *srec = P + H.off_site;
+    const float *lbv = P + H.off_lb, *ubv = P + H.off_ub, *qpos0 = P + H.off_qpos0;
+    const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
+
+    const int chain = (blockIdx.x * wpb + wave) * CPW + grp;
+    int st = chain < a.C ? LM_EVAL_X : LM_DONE;
+    int kind = a.do_root_opt ? 0 : 2;
+    int frame = 0, iter = 0, tries = 0;
+    float f = 0.0f, lam = L.lambda0, error = __builtin_inff();
+    uint32_t c_iter = 0, c_ls = 0, c_grad = 0, c_solves = 0;
+    float x[NQR], g[NQR], tr[NQR], q0[NQR];
+
+    if (lg == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 0.f; bx[3] = 1.f; bx[4] = 0.f; bx[5] = 0.f; bx[6] = 0.f; }
+    const size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
+#pragma unroll
+    for (int r = 0; r < NQR; ++r) {
+        const int e = r * G + lg;
+        float v = 0.f;
+        if (e < nq && st != LM_DONE) v = a.q_init ? a.q_init[(size_t)chain * nq + e] : qpos0[e];
+        q0[r] = v;
+    }
+    if (st != LM_DONE) {
+        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + i];
+        if (kind < 2) {
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                if (e < 3) q0[r] = a.kp[kp_chain + 3 * a.root_kp_idx + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; tr[r] = q0[r]; g[r] = 0.f; }
+    wave_sync();
+
+    while (__any(st != LM_DONE)) {
+        const int st_in = st;
+        const uint32_t mbits = MB[kind * G + lg], dbits = MB[nkinds * G + kind * G + lg];
+        const LmKind kh = *reinterpret_cast<const LmKind *>(KH + 8 * kind);
+
+        // ---- stage the point: x at the start of a solve, the trial point afterwards ---------------------------
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            if (e < nq) {
+                const float pt = st_in == LM_TRIAL ? tr[r] : x[r];
+                const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
+                qe[e] = (1.0f - mi) * q0[r] + mi * pt;
+            }
+        }
+        wave_sync();
+
+        // ---- forward kinematics (same operation sequence as the PG kernel) -----------------------------------------
+        for (int lev = 0; lev < H.nlev; ++lev) {
+            const int s_end = lev_adr[lev + 1];
+            for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
+                const float *br = brec + 12 * s;
+                const int4 bi = lds4i(br);
+                const float4 bp = lds4(br + 4);
+                const float *pp = bx + bi.x * 7;
+                const Q4 pquat = ld4(pp + 3);
+                V3 pos = add3(ld3(pp), rotate(V3{bp.x, bp.y, bp.z}, pquat));
+                Q4 quat = pquat;
+                if (!(bi.w & 1)) {
+                    const float4 bq = lds4(br + 8);
+                    quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
+                }
+                const int j1 = bi.y + bi.z;
+                for (int j = bi.y; j < j1; ++j) {
+                    const float *jr = jrec + 12 * j;
+                    const int4 ji = lds4i(jr);
+                    const float4 jp4 = lds4(jr + 4);
+                    const float4 ja4 = lds4(jr + 8);
+                    const int ty = ji.x, ad = ji.y;
+                    const V3 jp = {jp4.x, jp4.y, jp4.z}, jax = {ja4.x, ja4.y, ja4.z};
+                    V3 anchor;
+                    const Q4 prequat = quat;
+                    if (ty == JHINGE) {
+                        anchor = add3(rotate(jp, quat), pos);
+                        float sn, cs;
+                        sincos_((qe[ad] - jp4.w) * 0.5f, &sn, &cs);
+                        quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
+                        pos = sub3(anchor, rotate(jp, quat));
+                    } else if (ty == JFREE) {
+                        anchor = ld3(qe + ad);
+                        pos = anchor;
+                        float n;
+                        quat = normalize4(ld4(qe + ad + 3), &n);
+                        st4(qe + ad + 3, quat);
+                        jn[j] = n;
+                    } else if (ty == JSLIDE) {
+                        anchor = add3(rotate(jp, quat), pos);
+                        const V3 axis = rotate(jax, quat);
+                        const float d = qe[ad] - jp4.w;
+                        pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+                    } else {  // ball joints are rejected on the host for this solver
+                        anchor = pos;
+                    }
+                    st3(ja + 7 * j, anchor);
+                    st4(ja + 7 * j + 3, prequat);
+                }
+                st3(bx + (s + 1) * 7, pos);
+                st4(bx + (s + 1) * 7 + 3, quat);
+            }
+            wave_sync();
+        }
+
+        // ---- sites: world position (kept for the Jacobian), residual, loss term, wrench -------------------------------
+        const V3 cref = ld3(bx + 7);
+        const bool trunk_w = kind < 2;
+        const int Kpad = (K + 3) & ~3;
+        for (int k = K + lg; k < Kpad; k += G) r2[k] = 0.0f;
+        for (int k = lg; k < K; k += G) {
+            const float4 sr = lds4(srec + 4 * k);
+            const int ss = __builtin_bit_cast(int, sr.w);
+            const float *bp = bx + ((ss & 0xFFFF) + 1) * 7;
+            const V3 sx = add3(ld3(bp), rotate(V3{sr.x, sr.y, sr.z}, ld4(bp + 3)));
+            const float w = trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f;
+            const float rx = (kpl[3 * k] - sx.x) * w, ry = (kpl[3 * k + 1] - sx.y) * w, rz = (kpl[3 * k + 2] - sx.z) * w;
+            const V3 fv = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
+            const int sp = ss >> 16;
+            st3(sw + 6 * sp, fv);
+            st3(sw + 6 * sp + 3, cross3(sub3(sx, cref), fv));
+            st3(sxs + 3 * sp, sx);
+            r2[k] = FMA(rz, rz, FMA(ry, ry, rx * rx));
+        }
+        wave_sync();
+        float loss = 0.0f;
+        for (int i = 0; i < (Kpad >> 2); ++i) {
+            const float4 q4 = lds4(r2 + 4 * i);
+            loss += (q4.x + q4.y) + (q4.z + q4.w);
+        }
+        wave_sync();
+
+        // ---- gradient (joint pass); the world axis replaces the pre-joint quaternion in ja for the Jacobian --------------
+        for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
+        wave_sync();
+        for (int j = lg; j < H.naj; j += G) {
+            const float *jr = jrec + 12 * j;
+            const int4 ji = lds4i(jr);
+            const int ty = ji.x, ad = ji.y;
+            V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
+            for (int i = ji.z; i < ji.w; ++i) {
+                Fs = add3(Fs, ld3(sw + 6 * i));
+                T0 = add3(T0, ld3(sw + 6 * i + 3));
+            }
+            const V3 anchor = ld3(ja + 7 * j);
+            const Q4 prequat = ld4(ja + 7 * j + 3);
+            const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
+            if (ty == JHINGE || ty == JSLIDE) {
+                const float4 ja4 = lds4(jr + 8);
+                const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, prequat);
+                st3(ja + 7 * j + 3, axis);
+                gg[ad] = ty == JHINGE ? dot3(axis, tau) : dot3(axis, Fs);
+            } else if (ty == JFREE) {
+                st3(gg + ad, Fs);
+                const Q4 qh = ld4(qe + ad + 3);
+                const V3 u = {qh.x, qh.y, qh.z};
+                const V3 uxt = cross3(u, tau);
+                const float n = jn[j];
+                const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
+                gg[ad + 3] = (-2.0f * dot3(tau, u)) / dn;
+                gg[ad + 4] = (2.0f * FMA(qh.w, tau.x, -uxt.x)) / dn;
+                gg[ad + 5] = (2.0f * FMA(qh.w, tau.y, -uxt.y)) / dn;
+                gg[ad + 6] = (2.0f * FMA(qh.w, tau.z, -uxt.z)) / dn;
+            }
+        }
+        wave_sync();
+        float gnew[NQR];
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            gnew[r] = (e < nq && ((mbits >> r) & 1u)) ? gg[e] : 0.0f;
+        }
+
+        // ---- accept / reject, stopping test --------------------------------------------------------------------------------
+        bool ending = false, need_system = false;
+        if (st_in != LM_DONE) {
+            c_grad++;
+            const bool first = st_in == LM_EVAL_X;
+            if (!first) c_ls++;
+            if (first || loss < f) {
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) { if (!first) x[r] = tr[r]; g[r] = gnew[r]; }
+                f = loss;
+                tries = 0;
+                if (!first) {
+                    lam = lam * 0.5f;
+                    if (lam < 1e-9f) lam = 1e-9f;
+                    iter++;
+                }
+                need_system = true;
+            } else {
+                lam = lam * 4.0f;
+                tries++;
+                if (tries >= 8) ending = true;  // no decrease found: keep x
+            }
+        }
+        {
+            float t0[NQR];
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                float a0 = 0.0f;
+                if (e < nq) {
+                    const float d = clipf(x[r] - g[r], lbv[e], ubv[e]) - x[r];
+                    a0 = d * d;
+                }
+                t0[r] = a0;
+            }
+            const float e2 = group_tree_sum<G, NQR>(t0);
+            if (need_system) {
+                error = __builtin_sqrtf(e2);
+                if (!(error > a.tol) || iter >= a.maxiter || kh.nd == 0) { ending = true; need_system = false; }
+            }
+        }
+
+        // ---- Gauss-Newton system of the accepted point ----------------------------------------------------------------------
+        const int n = kh.nd;
+        if (__any(need_system)) {
+            if (need_system) {
+                // weighted Jacobian blocks of every (site, dof on its root path)
+                for (int it = lg; it < kh.ni; it += G) {
+                    const int4 rec = *reinterpret_cast<const int4 *>(L.tab + kh.off_item + 4 * it);
+                    const int4 dr = *reinterpret_cast<const int4 *>(L.tab + kh.off_dof + 4 * rec.y);
+                    const int j = dr.y, comp = dr.z;
+                    const float *jr = jrec + 12 * j;
+                    const int ty = reinterpret_cast<const int *>(jr)[0];
+                    const V3 d = sub3(ld3(sxs + 3 * rec.x), ld3(ja + 7 * j));
+                    V3 col;
+                    if (ty == JHINGE) col = cross3(ld3(ja + 7 * j + 3), d);
+                    else if (ty == JSLIDE) col = ld3(ja + 7 * j + 3);
+                    else if (comp < 3) col = {comp == 0 ? 1.f : 0.f, comp == 1 ? 1.f : 0.f, comp == 2 ? 1.f : 0.f};
+                    else {
+                        const int ad = reinterpret_cast<const int *>(jr)[1];
+                        const Q4 qh = ld4(qe + ad + 3);
+                        const V3 u = {qh.x, qh.y, qh.z};
+                        const float nn = jn[j];
+                        const float dn = nn + (nn == 0.0f ? 1e-6f : 0.0f);
+                        if (comp == 3) {
+                            const V3 c = cross3(u, d);
+                            col = {(-2.0f * c.x) / dn, (-2.0f * c.y) / dn, (-2.0f * c.z) / dn};
+                        } else {
+                            const V3 e = {comp == 4 ? 1.f : 0.f, comp == 5 ? 1.f : 0.f, comp == 6 ? 1.f : 0.f};
+                            const V3 exd = cross3(e, d), t2 = cross3(cross3(e, u), d);
+                            col = {(2.0f * (qh.w * exd.x - t2.x)) / dn, (2.0f * (qh.w * exd.y - t2.y)) / dn,
+                                   (2.0f * (qh.w * exd.z - t2.z)) / dn};
+                        }
+                    }
+                    // site weight (0/1): trunk mask in the root passes, all ones otherwise
+                    const float w = trunk_w ? (a.kpw_sorted[rec.x] ? 1.f : 0.f) : 1.0f;
+                    st3(Jp + (rec.x * kh.maxpd + rec.z) * 3, V3{col.x * w, col.y * w, col.z * w});
+                }
+                for (int i = lg; i < L.npk; i += G) Ap[i] = 0.0f;
+            }
+            wave_sync();
+            if (need_system) {
+                for (int en = lg; en < kh.ne; en += G) {
+                    const int4 rec = *reinterpret_cast<const int4 *>(L.tab + kh.off_ent + 4 * en);
+                    const int pr = rec.z & 0xFF, pc = rec.z >> 8, lo = rec.w & 0xFFFF, hi = rec.w >> 16;
+                    float s = 0.0f;
+                    for (int i = lo; i < hi; ++i)
+                        s += dot3(ld3(Jp + (i * kh.maxpd + pr) * 3), ld3(Jp + (i * kh.maxpd + pc) * 3));
+                    Ap[pk(rec.x, rec.y)] = s;
+                }
+                for (int d = lg; d < n; d += G) {
+                    const int e = L.tab[kh.off_dof + 4 * d];
+                    const float b = -0.5f * gg[e];
+                    bv[d] = b;
+                    const float xe = qe[e];  // the accepted point (root quaternion normalised: never at +-1 unless axis-aligned)
+                    fz[d] = ((xe <= lbv[e] && b < 0.0f) || (xe >= ubv[e] && b > 0.0f)) ? 1.0f : 0.0f;
+                }
+            }
+            wave_sync();
+            if (need_system && kh.quat0 >= 0 && lg < 10) {
+                // gauge: the length of the raw root quaternion does not change the pose -- make that direction stiff
+                int c = 0, e = lg;
+                while (e > c) { e -= c + 1; ++c; }  // lg -> (c, e), e <= c < 4
+                const int ad = L.tab[kh.off_dof + 4 * kh.quat0];
+                Ap[pk(kh.quat0 + c, kh.quat0 + e)] += qe[ad + c] * qe[ad + e];
+            }
+            wave_sync();
+        }
+
+        // ---- damped, bound-aware system -> Cholesky -> step -> trial point ---------------------------------------------------
+        const bool solving = (st_in != LM_DONE) && !ending;
+        if (__any(solving)) {
+            if (solving) {
+                for (int i = lg; i < n; i += G) {
+                    const bool fi = fz[i] != 0.0f;
+                    for (int j = 0; j <= i; ++j) {
+                        float v = Ap[pk(i, j)];
+                        if (fi || fz[j] != 0.0f) v = 0.0f;
+                        if (j == i) v = fi ? 1.0f : FMA(v, lam, v) + 1e-9f;
+                        Hc[pk(i, j)] = v;
+                    }
+                }
+            }
+            wave_sync();
+            // left-looking Cholesky, column by column; every lane recomputes the pivot (broadcast reads).
+            // Groups of one wave may have different n (different solve kinds): wave_sync is a fence, not a barrier.
+            bool bad = false;
+            if (solving) {
+                for (int j = 0; j < n; ++j) {
+                    float s = Hc[pk(j, j)];
+                    for (int k = 0; k < j; ++k) { const float v = Hc[pk(j, k)]; s = FMA(-v, v, s); }
+                    if (!(s > 0.0f)) { bad = true; s = 1.0f; }
+                    const float ljj = __builtin_sqrtf(s);
+                    for (int i = j + 1 + lg; i < n; i += G) {
+                        float t = Hc[pk(i, j)];
+                        for (int k = 0; k < j; ++k) t = FMA(-Hc[pk(i, k)], Hc[pk(j, k)], t);
+                        Hc[pk(i, j)] = t / ljj;
+                    }
+                    wave_sync();
+                    if (lg == 0) Hc[pk(j, j)] = ljj;
+                    wave_sync();
+                }
+                // forward substitution L y = b (column oriented), then backward L^T d = y
+                for (int i = lg; i < n; i += G) dv[i] = fz[i] != 0.0f ? 0.0f : bv[i];
+                wave_sync();
+                for (int k = 0; k < n; ++k) {
+                    const float yk = dv[k] / Hc[pk(k, k)];
+                    wave_sync();
+                    if (lg == 0) dv[k] = yk;
+                    for (int i = k + 1 + lg; i < n; i += G) dv[i] = FMA(-Hc[pk(i, k)], yk, dv[i]);
+                    wave_sync();
+                }
+                for (int i = n - 1; i >= 0; --i) {
+                    const float di = dv[i] / Hc[pk(i, i)];
+                    wave_sync();
+                    if (lg == 0) dv[i] = di;
+                    for (int k = lg; k < i; k += G) dv[k] = FMA(-Hc[pk(i, k)], di, dv[k]);
+                    wave_sync();
+                }
+            }
+            wave_sync();
+            if (solving) {
+                if (bad) {  // not positive definite at this damping: treat as a rejected step
+                    lam = lam * 4.0f;
+#pragma unroll
+                    for (int r = 0; r < NQR; ++r) tr[r] = x[r];
+                } else {
+                    // scatter the step to qpos order through gg (consumed), then the clipped trial point
+                    for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
+                }
+            }
+            wave_sync();
+            if (solving && !bad)
+                for (int d = lg; d < n; d += G) gg[L.tab[kh.off_dof + 4 * d]] = dv[d];
+            wave_sync();
+            if (solving && !bad) {
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    tr[r] = (e < nq && ((dbits >> r) & 1u)) ? clipf(x[r] + gg[e], lbv[e], ubv[e]) : x[r];
+                }
+            }
+            if (solving) st = LM_TRIAL;
+            wave_sync();
+        }
+
+        // ---- end of a solve: replace_qs, next solve / next frame (same sequencing as the PG kernel) ----------------------------
+        if (__any(ending)) {
+            if (ending) {
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    if (e < nq) {
+                        const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
+                        qe[e] = (kind != 2) ? ((1.0f - mi) * q0[r] + mi * x[r]) : x[r];
+                    }
+                }
+            }
+            wave_sync();
+            if (ending) {
+                for (int qi = lg; qi < H.nquat; qi += G) {
+                    const int ad = quat_adr[qi];
+                    float nn;
+                    st4(qe + ad, normalize4(ld4(qe + ad), &nn));
+                }
+            }
+            wave_sync();
+            if (ending) {
+                c_iter += iter;
+                c_solves++;
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    if (e < nq) q0[r] = qe[e];
+                }
+                if (kind < 2) c_iter = c_ls = c_grad = c_solves = 0;
+                kind++;
+                if (kind > a.P + 2) {
+                    const size_t fo = (size_t)chain * a.F + frame;
+                    for (int e = lg; e < nq; e += G) a.qpos_out[fo * nq + e] = qe[e];
+                    if (lg == 0) {
+                        a.err_out[fo] = error;
+                        if (a.counters_out) {
+                            uint32_t *co = a.counters_out + fo * 4;
+                            co[0] = c_iter; co[1] = c_ls; co[2] = c_grad; co[3] = c_solves;
+                        }
+                    }
+                    c_iter = c_ls = c_grad = c_solves = 0;
+                    frame++;
+                    kind = 2;
+                    if (frame >= a.F) {
+                        if (a.q_carry_out)
+                            for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
+                        st = LM_DONE;
+                    } else {
+                        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
+                    }
+                } else if (kind < 2) {
+#pragma unroll
+                    for (int r = 0; r < NQR; ++r) {
+                        const int e = r * G + lg;
+                        if (e < 3) q0[r] = kpl[3 * a.root_kp_idx + e];
+                    }
+                }
+                if (st != LM_DONE) {
+#pragma unroll
+                    for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; tr[r] = q0[r]; }
+                    lam = L.lambda0; iter = 0; tries = 0;
+                    error = __builtin_inff();
+                    st = LM_EVAL_X;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+template <int G, int NQR>
+static hipError_t launch_lm(const QArgs &a, const LmArgs &L, int wpb, size_t lds_bytes, hipStream_t s) {
+    constexpr int CPW = 64 / G;
+    const int per_block = CPW * wpb;
+    const int blocks = (a.C + per_block - 1) / per_block;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_lm_kernel<G, NQR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((q_phase_lm_kernel<G, NQR>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
+                             int *capacity_out) {
+    const int nq = a.h.nq;
+    *capacity_out = 0;
+#define STAC_TRY(GG, RR)                                    \
+    if (G == GG && nq <= GG * RR) {                         \
+        *capacity_out = GG * RR;                            \
+        return launch_lm<GG, RR>(a, L, wpb, lds_bytes, s);  \
+    }
+    STAC_TRY(16, 5) STAC_TRY(16, 8) STAC_TRY(16, 16)
+    STAC_TRY(32, 3) STAC_TRY(32, 8)
+    STAC_TRY(64, 2) STAC_TRY(64, 4)
+#undef STAC_TRY
+    return hipErrorInvalidValue;
+}
+
+}  // namespace stac

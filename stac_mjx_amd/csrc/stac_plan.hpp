@@ -86,6 +86,7 @@ struct QArgs {
     const uint8_t *masks;   // device [nkinds, nqpad] bytes: kind 0,1 = root passes, 2 = full, 3.. = parts
     const uint8_t *kpw;     // device [2, K] bytes: row 0 = trunk mask (root passes), row 1 = all ones / single-solve mask
     const uint8_t *kpw3;    // device [3K] per-coordinate mask for single-solve mode (or null)
+    const uint8_t *kpw_sorted;  // device [K] trunk mask by sorted-site position (LM solver)
     int32_t C, F, P;
     int32_t root_kp_idx, do_root_opt;
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
@@ -99,6 +100,37 @@ struct QArgs {
     uint32_t *counters_out; // [C,F,4] or null
     float *q_carry_out;     // [C,nq] or null
     unsigned long long *prof;  // diagnostic builds (-DSTAC_PROFILE) only: [16] per-phase cycle sums
+};
+
+// ---- optional LM solver (stac_lm.hip): per solve-kind tables in one global-memory blob of 32-bit words -----
+struct LmKind {            // 8 words, at blob[kind * 8]
+    int32_t nd;            // optimised coordinates with structural support ("dofs"), in qpos order
+    int32_t ne;            // structurally non-zero entries (row >= col) of J^T J
+    int32_t ni;            // (site, dof) pairs with a non-zero Jacobian block
+    int32_t maxpd;         // longest root path, counted in dofs
+    int32_t off_dof;       // LmDof[nd]
+    int32_t off_ent;       // LmEnt[ne], longest site range first
+    int32_t off_item;      // LmItem[ni]
+    int32_t quat0;         // index of the first raw root-quaternion dof when all four are optimised, else -1
+};
+struct LmDof { int32_t qadr, joint, comp, pd; };                 // qpos index, active joint, component, path depth
+struct LmEnt { int32_t row, col, pds, range; };                  // pds = pd_row | pd_col << 8; range = lo | hi << 16
+struct LmItem { int32_t sitepos, dof, pd, pad; };
+struct LmArgs {
+    const int32_t *tab;    // device blob: LmKind[nkinds] then the records
+    int32_t nkinds;
+    int32_t n_max;         // max nd over kinds
+    int32_t npk;           // n_max (n_max + 1) / 2 rounded up to a multiple of 4
+    int32_t maxpd;         // max over kinds
+    float lambda0;
+    // extra per-chain LDS regions (float offsets inside the chain region, after the PG layout)
+    int32_t c_sx;          // [3K] site world positions by sorted-site position
+    int32_t c_jp;          // [K * maxpd * 3] weighted Jacobian blocks; aliased by the Cholesky factor H[npk]
+    int32_t c_A;           // [npk] packed lower triangle of J^T W J (+ gauge term)
+    int32_t c_b;           // [n_max] J^T W (kp - x)
+    int32_t c_d;           // [n_max] step
+    int32_t c_fz;          // [n_max] 1.0 where the coordinate is frozen at a bound
+    int32_t chain_stride;  // PG stride + extras (odd)
 };
 
 }  // namespace stac

@@ -33,7 +33,11 @@ class StacModelTables(C.Structure):
 
 
 class StacQParams(C.Structure):
-    _fields_ = [("tol", C.c_float), ("maxiter", C.c_int32), ("maxls", C.c_int32), ("lanes_per_chain", C.c_int32)]
+    _fields_ = [("tol", C.c_float), ("maxiter", C.c_int32), ("maxls", C.c_int32), ("lanes_per_chain", C.c_int32),
+                ("solver", C.c_int32), ("lm_lambda0", C.c_float)]
+
+
+SOLVERS = {"pg": 0, "lm": 1}  # STAC_SOLVER_PG (the reference's algorithm, parity mode) / STAC_SOLVER_LM
 
 
 class StacHipError(RuntimeError):
@@ -94,14 +98,19 @@ def _host_u8(a, n):
 class Engine:
     """One compiled model resident on one GPU."""
 
-    def __init__(self, tables, lb, ub, *, tol=1e-4, maxiter=400, maxls=15, lanes_per_chain=0, device=None):
+    def __init__(self, tables, lb, ub, *, tol=1e-4, maxiter=400, maxls=15, lanes_per_chain=0, device=None,
+                 solver="pg", lm_maxiter=40, lm_lambda0=1e-2):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise StacHipError("no GPU visible: the STAC engine has no CPU fallback")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         torch.cuda.set_device(self.device)
         self.nq, self.nbody, self.njnt, self.K = tables.nq, tables.nbody, tables.njnt, tables.nsite
-        self.params = StacQParams(float(tol), int(maxiter), int(maxls), int(lanes_per_chain))
+        self.params = StacQParams(float(tol), int(maxiter), int(maxls), int(lanes_per_chain), SOLVERS["pg"], 0.0)
+        # q_phase may use the optional LM solver; q_solve (the StacCore.q_opt seam) always runs the reference's PG
+        self.phase_params = StacQParams(float(tol), int(lm_maxiter if solver == "lm" else maxiter), int(maxls),
+                                        int(lanes_per_chain), SOLVERS[solver], float(lm_lambda0))
+        self.solver = solver
         t = StacModelTables()
         t.nbody, t.njnt, t.nq, t.nsite = tables.nbody, tables.njnt, tables.nq, tables.nsite
         keep = {}
@@ -153,6 +162,7 @@ class Engine:
 
     def set_lanes_per_chain(self, g: int):
         self.params.lanes_per_chain = int(g)
+        self.phase_params.lanes_per_chain = int(g)
 
     # -- offsets ------------------------------------------------------------------------------
     def set_site_pos(self, offsets):
@@ -217,8 +227,10 @@ class Engine:
             "xquat": (o.get("xquat") if o.get("xquat") is not None else mk(Cn, F, self.nbody, 4)) if want_bodies else None,
             "marker_sites": (o.get("marker_sites") if o.get("marker_sites") is not None else mk(Cn, F, self.K, 3)) if want_markers else None,
         }
+        if self.solver == "pg":  # StacCore may have updated tol / maxiter on self.params
+            self.phase_params.tol, self.phase_params.maxiter = self.params.tol, self.params.maxiter
         self._check(self.lib.stac_q_phase(
-            self._h, C.byref(self.params), _ptr(kp), _ptr(qi), pm.ctypes.data_as(_u8p) if P else None,
+            self._h, C.byref(self.phase_params), _ptr(kp), _ptr(qi), pm.ctypes.data_as(_u8p) if P else None,
             tk.ctypes.data_as(_u8p), Cn, F, P, int(root_kp_idx), int(root_dims), 1 if do_root_opt else 0,
             _ptr(res["qpos"]), _ptr(res["frame_error"]), _ptr(res["counters"]), _ptr(res["carry_qpos"]),
             _ptr(res["xpos"]), _ptr(res["xquat"]), _ptr(res["marker_sites"]), self._stream()))  # fmt: skip

@@ -363,3 +363,36 @@ def test_errors_are_loud(rodent_setup):
         eng.q_phase(np.zeros((1, 1, 69), np.float32), part_masks=[])
     with pytest.raises(ValueError):
         _engine(fs).q_phase(np.zeros((1, 1, 68), np.float32), part_masks=[])
+
+
+# ---- optional LM solver (STAC_SOLVER_LM; not the reference's algorithm) vs its oracle statement ---------------------------------
+TOL_LM_MARKERS = 5e-4   # metres; LM iterates are not reproduced bit for bit (different factorisation order)
+
+
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_lm_q_phase_matches_oracle_lm_in_marker_space(rodent_setup, rodent_mocap, lanes):
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    fs = rodent_setup
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, solver="lm", lm_maxiter=40, lanes_per_chain=lanes)
+    orc = Oracle(fs.tables, tol=1e-4)
+    kp = rodent_mocap[::40][:10].reshape(5, 2, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    ref = orc.ik_clips_lm(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    pg = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    mk, q = _np(res["marker_sites"]), _np(res["qpos"])
+    tgt = kp.reshape(5, 2, 23, 3)
+    e_hip = np.linalg.norm(mk - tgt, axis=-1).mean()
+    e_ref = np.linalg.norm(ref["marker_sites"] - tgt, axis=-1).mean()
+    e_pg = np.linalg.norm(pg["marker_sites"] - tgt, axis=-1).mean()
+    assert np.abs(mk - ref["marker_sites"]).max() <= TOL_LM_MARKERS
+    assert abs(e_hip - e_ref) <= 2e-5 and e_hip <= e_pg + 1e-5
+    assert (_np(res["frame_error"]) <= 1e-4).all()
+    assert (q >= fs.lb - 1e-6).all() and (q <= fs.ub + 1e-6).all()
+    # outputs are self-consistent: FK(qpos_out) == markers_out
+    fk = eng.fk(res["qpos"].reshape(-1, 74))
+    np.testing.assert_allclose(_np(fk["site_xpos"]), mk.reshape(-1, 23, 3), atol=3e-7, rtol=0)
+    it = _np(res["counters"])[..., 0].mean()
+    assert it < 60, it

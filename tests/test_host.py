@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = load_library()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.stac_abi_version() == 1
+    assert lib.stac_abi_version() == 2
     assert lib.stac_device_count() >= 0
 
 

@@ -317,3 +317,34 @@ def test_pg_residuals_in_the_range_the_reference_printed(orc, rodent_setup, rode
     mean = float(out["frame_error"].mean())
     assert 0.5 * 3.554e-05 <= mean <= 2.0 * 3.554e-05, mean
     assert (out["frame_error"] <= 1e-4).all()  # every frame's last (head) solve converged, like the reference's
+
+
+# ---- optional LM solver (not the reference's algorithm): the oracle side ---------------------------------------------------
+def test_lm_converges_and_fits_at_least_as_well_as_pg(orc, rodent_setup, rodent_mocap):
+    fs = rodent_setup
+    kp = rodent_mocap[::50][:12].reshape(12, 1, 69)
+    lm = orc.ik_clips_lm(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, want_bodies=False)
+    pg = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, want_bodies=False)
+    tgt = kp.reshape(12, 1, 23, 3)
+    e_lm = np.linalg.norm(lm["marker_sites"] - tgt, axis=-1).mean()
+    e_pg = np.linalg.norm(pg["marker_sites"] - tgt, axis=-1).mean()
+    assert e_lm <= e_pg + 1e-5, (e_lm, e_pg)
+    assert (lm["frame_error"] <= 1e-4).all()  # converged to the same stopping residual the PG solver uses
+    assert lm["counters"][..., 2].mean() < 0.05 * (pg["counters"][..., 1] + pg["counters"][..., 2]).mean()
+    q = lm["qpos"][:, 0]
+    assert (q >= fs.lb - 1e-6).all() and (q <= fs.ub + 1e-6).all()
+    np.testing.assert_allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0, atol=1e-5)
+
+
+def test_lm_single_solve_matches_f64_twin_in_marker_space(rodent_setup, rodent_mocap):
+    fs = rodent_setup
+    o32, o64 = Oracle(fs.tables), Oracle(fs.tables, precision="f64")
+    kp = rodent_mocap[10]
+    q0 = fs.tables.qpos0.copy()
+    q0[:3] = kp[3 * fs.root_kp_idx: 3 * fs.root_kp_idx + 3]
+    allq, allk = np.ones(74, bool), np.ones(69, bool)
+    x32, s32 = o32.q_opt_lm(kp, allq, allk, q0, fs.lb, fs.ub)
+    x64, s64 = o64.q_opt_lm(kp, allq, allk, q0, fs.lb, fs.ub)
+    assert s32["error"] <= 1e-4 and s64["error"] <= 1e-4 and s32["iter_num"] < 40
+    m32, m64 = o32.fk(x32)["site_xpos"], o64.fk(x64)["site_xpos"]
+    assert np.abs(m32 - m64).max() < 5e-4 and abs(s32["loss"] - s64["loss"]) < 1e-3 * s64["loss"]
