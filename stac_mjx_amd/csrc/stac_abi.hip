@@ -487,8 +487,8 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     const PlanHeader &h = m->h;
     const int naj = h.naj, nab = h.nab;
     if (h.has_ball) return fail(STAC_ERR_INVALID, "STAC_SOLVER_LM does not support ball joints");
-    std::vector<int32_t> tab((size_t)nkinds * 8, 0);
-    int n_max = 0, maxpd_all = 1;
+    std::vector<int32_t> tab((size_t)nkinds * kLmKindWords, 0), hot, cold;
+    int n_max = 0, maxpd_all = 1, npk_max = 4;
     auto is_anc_or_self = [&](int sa, int sb) {  // slot sa ancestor-or-equal of slot sb
         for (int s2 = sb; s2 >= 0; s2 = m->h_ab_parent[s2] - 1) if (s2 == sa) return true;
         return false;
@@ -505,6 +505,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
         }
         const int nd = (int)D.size();
         std::vector<int32_t> ents, items;
+        std::vector<std::vector<int>> paths(nd);
         int maxpd = 1;
         struct Ent { int row, col, pds, range, len; };
         std::vector<Ent> E;
@@ -516,6 +517,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
                 if (a2 == b || is_anc_or_self(m->h_aj_slot[D[a2].joint], sb)) path.push_back(a2);
             pd = (int)path.size() - 1;
             D[b].pd = pd;
+            paths[b] = path;
             maxpd = std::max(maxpd, pd + 1);
             const int lo = m->h_aj_slo[jb], hi = m->h_aj_shi[jb];
             for (int pi = 0; pi < (int)path.size(); ++pi)
@@ -529,22 +531,33 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
         for (int b = 0; b + 3 < nd; ++b)
             if (m->h_aj_type[D[b].joint] == STAC_JNT_FREE && D[b].comp == 3 && D[b + 3].joint == D[b].joint && D[b + 3].comp == 6)
                 quat0 = b;
-        int32_t *kh = tab.data() + (size_t)kind * 8;
-        kh[0] = nd; kh[1] = (int)E.size(); kh[2] = (int)items.size() / 4; kh[3] = maxpd;
-        kh[4] = (int)tab.size();
-        for (const Dof &d : D) { tab.push_back(d.qadr); tab.push_back(d.joint); tab.push_back(d.comp); tab.push_back(d.pd); }
-        kh = tab.data() + (size_t)kind * 8;
-        kh[5] = (int)tab.size();
-        tab.insert(tab.end(), ents.begin(), ents.end());
-        kh = tab.data() + (size_t)kind * 8;
-        kh[6] = (int)tab.size();
-        tab.insert(tab.end(), items.begin(), items.end());
-        kh = tab.data() + (size_t)kind * 8;
-        kh[7] = quat0;
+        const size_t kho = (size_t)kind * kLmKindWords;
+        tab[kho + 0] = nd; tab[kho + 1] = (int)E.size(); tab[kho + 2] = (int)items.size() / 4; tab[kho + 3] = maxpd;
+        tab[kho + 7] = quat0;
+        // hot section (LDS): dof records + path table; cold section (global): entries + items
+        tab[kho + 4] = (int)hot.size();
+        for (const Dof &d : D) { hot.push_back(d.qadr); hot.push_back(d.joint); hot.push_back(d.comp); hot.push_back(d.pd); }
+        tab[kho + 8] = (int)hot.size();
+        for (int b = 0; b < nd; ++b)
+            for (int pi = 0; pi < maxpd; ++pi) hot.push_back(pi < (int)paths[b].size() ? paths[b][pi] : -1);
+        while (hot.size() & 3) hot.push_back(0);
+        tab[kho + 5] = (int)cold.size();
+        cold.insert(cold.end(), ents.begin(), ents.end());
+        tab[kho + 6] = (int)cold.size();
+        cold.insert(cold.end(), items.begin(), items.end());
         n_max = std::max(n_max, nd);
         maxpd_all = std::max(maxpd_all, maxpd);
+        npk_max = std::max(npk_max, nd * maxpd);
     }
     (void)nab;
+    const int hot_off = (int)tab.size(), hot_words = (int)hot.size();
+    const int cold_off = hot_off + hot_words;
+    for (int kind = 0; kind < nkinds; ++kind) {  // cold offsets become absolute
+        tab[(size_t)kind * kLmKindWords + 5] += cold_off;
+        tab[(size_t)kind * kLmKindWords + 6] += cold_off;
+    }
+    tab.insert(tab.end(), hot.begin(), hot.end());
+    tab.insert(tab.end(), cold.begin(), cold.end());
     if (tab != m->lm_tab_cache) {
         if (tab.size() > m->lm_tab_words) {
             if (m->d_lm_tab) (void)hipFree(m->d_lm_tab);
@@ -559,8 +572,11 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     LmArgs &L = m->lm_args;
     L.tab = m->d_lm_tab;
     L.nkinds = nkinds;
+    L.hot_off = hot_off;
+    L.hot_words = hot_words;
     L.n_max = std::max(n_max, 1);
-    L.npk = ((L.n_max * (L.n_max + 1)) / 2 + 3) & ~3;
+    if (L.n_max > 192) return fail(STAC_ERR_CAPACITY, "more than 192 optimised coordinates: not supported by the LM solver");
+    L.npk = (npk_max + 3) & ~3;
     L.maxpd = maxpd_all;
     L.lambda0 = lambda0 > 0.0f ? lambda0 : 1e-2f;
     int o = h.chain_stride;
@@ -588,13 +604,20 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     a.h = m->h;
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const LmArgs &L = m->lm_args;
+#ifdef STAC_PROFILE
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) { (void)hipMalloc(reinterpret_cast<void **>(&d_prof), 16 * sizeof(unsigned long long)); }
+    (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), s);
+    a.prof = d_prof;
+#endif
     int G = (p->lanes_per_chain == 16 || p->lanes_per_chain == 32 || p->lanes_per_chain == 64) ? p->lanes_per_chain
             : (nchains >= 1024 ? 16 : 64);
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
     for (; !cap && G <= 64; G *= 2) {
         const int cpw = 64 / G;
-        const int mbw = (2 * nkinds * G + 3) & ~3, khw = (nkinds * 8 + 3) & ~3;
+        const int mbw = (2 * nkinds * G + 3) & ~3, khw = ((nkinds * kLmKindWords + 3) & ~3) + ((L.hot_words + 3) & ~3) +
+                                                   ((((L.maxpd * (L.maxpd + 1)) >> 1) + 3) & ~3);
         auto lds_for = [&](int wpb) { return (size_t)(((m->h.total_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
         int wpb = 0, best_waves = 0;
         for (int w = 1; w <= 4; ++w) {
@@ -614,6 +637,19 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the LM q_phase kernel limits (LDS per CU / nq)");
     if (e != hipSuccess) return fail(STAC_ERR_HIP, std::string("q_phase LM launch: ") + hipGetErrorString(e));
+#ifdef STAC_PROFILE
+    {
+        unsigned long long hh[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hh, a.prof, sizeof(hh), hipMemcpyDeviceToHost);
+        static const char *names[] = {"loop", "stage_fk", "sites_loss", "gradient", "accept", "jac_blocks", "jtj", "damp", "ltdl", "fwd", "trial", "end"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += hh[i];
+        fprintf(stderr, "[stac profile LM]");
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)hh[i] / (double)(tot ? tot : 1));
+        fprintf(stderr, " total_wave_cycles=%.3g\n", (double)tot);
+    }
+#endif
     return STAC_OK;
 }
 

@@ -21,7 +21,29 @@ namespace stac {
 
 enum : int { LM_EVAL_X = 0, LM_TRIAL = 1, LM_DONE = 3 };
 
-__device__ __forceinline__ int pk(int i, int j) { return (i * (i + 1)) / 2 + j; }  // packed lower triangle, j <= i
+
+// Jacobian block d(site position)/d(dof): one column of the 3 x nd site Jacobian.
+struct DofGeom {
+    int ty, comp;
+    V3 anchor, axis;  // joint anchor and world axis (hinge / slide)
+    Q4 qh;            // normalised root quaternion (free joint)
+    float dn;         // |q| (+1e-6 if 0)
+};
+__device__ __forceinline__ V3 jac_col(const DofGeom &g, V3 sx) {
+    const V3 d = sub3(sx, g.anchor);
+    if (g.ty == JHINGE) return cross3(g.axis, d);
+    if (g.ty == JSLIDE) return g.axis;
+    if (g.comp < 3) return {g.comp == 0 ? 1.f : 0.f, g.comp == 1 ? 1.f : 0.f, g.comp == 2 ? 1.f : 0.f};
+    const V3 u = {g.qh.x, g.qh.y, g.qh.z};
+    if (g.comp == 3) {
+        const V3 c = cross3(u, d);
+        return {(-2.0f * c.x) / g.dn, (-2.0f * c.y) / g.dn, (-2.0f * c.z) / g.dn};
+    }
+    const V3 e = {g.comp == 4 ? 1.f : 0.f, g.comp == 5 ? 1.f : 0.f, g.comp == 6 ? 1.f : 0.f};
+    const V3 exd = cross3(e, d), t2 = cross3(cross3(e, u), d);
+    return {(2.0f * (g.qh.w * exd.x - t2.x)) / g.dn, (2.0f * (g.qh.w * exd.y - t2.y)) / g.dn,
+            (2.0f * (g.qh.w * exd.z - t2.z)) / g.dn};
+}
 
 template <int G, int NQR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -40,7 +62,15 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     uint32_t *MB = reinterpret_cast<uint32_t *>(lds + plan_words);  // [2][nkinds][G]: qs_to_opt bits, dof bits
     const int nkinds = a.P + 3;
     int *KH = reinterpret_cast<int *>(lds + plan_words + a.mb_words);  // LmKind[nkinds]
-    for (int i = threadIdx.x; i < nkinds * 8; i += blockDim.x) KH[i] = L.tab[i];
+    for (int i = threadIdx.x; i < nkinds * kLmKindWords; i += blockDim.x) KH[i] = L.tab[i];
+    const int khh_words = (nkinds * kLmKindWords + 3) & ~3;
+    int *KT = KH + khh_words;  // hot tables of every kind: dof records and root-path tables (walked in dependent loops)
+    for (int i = threadIdx.x; i < L.hot_words; i += blockDim.x) KT[i] = L.tab[L.hot_off + i];
+    // TRI[q] = (row << 8 | col) of the q-th entry of a packed lower triangle (pair enumeration of the L^T D L step)
+    int *TRI = KT + ((L.hot_words + 3) & ~3);
+    const int ntri = (L.maxpd * (L.maxpd + 1)) >> 1;
+    for (int r = threadIdx.x; r < L.maxpd; r += blockDim.x)
+        for (int c = 0; c <= r; ++c) TRI[((r * (r + 1)) >> 1) + c] = (r << 8) | c;
     __syncthreads();
     for (int i = threadIdx.x; i < nkinds * G; i += blockDim.x) {
         const int kind = i / G, l = i % G;
@@ -49,15 +79,15 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             const int e = r * G + l;
             if (e < nq && a.masks[kind * nqpad + e]) bits |= (1u << r);
         }
-        const LmKind *kh = reinterpret_cast<const LmKind *>(KH + 8 * kind);
+        const LmKind *kh = reinterpret_cast<const LmKind *>(KH + kLmKindWords * kind);
         for (int d = 0; d < kh->nd; ++d) {
-            const int e = L.tab[kh->off_dof + 4 * d];
+            const int e = KT[kh->off_dof + 4 * d];
             if (e % G == l) dbits |= (1u << (e / G));
         }
         MB[i] = bits;
         MB[nkinds * G + i] = dbits;
     }
-    const int kh_words = (nkinds * 8 + 3) & ~3;
+    const int kh_words = khh_words + ((L.hot_words + 3) & ~3) + ((ntri + 3) & ~3);
     float *CB = lds + plan_words + a.mb_words + kh_words + (wave * CPW + grp) * L.chain_stride;
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn;
     float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
@@ -102,10 +132,12 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; tr[r] = q0[r]; g[r] = 0.f; }
     wave_sync();
 
+    PROF_DECL;
     while (__any(st != LM_DONE)) {
+        PROF_TICK(0);
         const int st_in = st;
         const uint32_t mbits = MB[kind * G + lg], dbits = MB[nkinds * G + kind * G + lg];
-        const LmKind kh = *reinterpret_cast<const LmKind *>(KH + 8 * kind);
+        const LmKind kh = *reinterpret_cast<const LmKind *>(KH + kLmKindWords * kind);
 
         // ---- stage the point: x at the start of a solve, the trial point afterwards ---------------------------
 #pragma unroll
@@ -174,6 +206,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             wave_sync();
         }
 
+        PROF_TICK(1);  // stage + FK
         // ---- sites: world position (kept for the Jacobian), residual, loss term, wrench -------------------------------
         const V3 cref = ld3(bx + 7);
         const bool trunk_w = kind < 2;
@@ -201,6 +234,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
         }
         wave_sync();
 
+        PROF_TICK(2);  // sites + loss
         // ---- gradient (joint pass); the world axis replaces the pre-joint quaternion in ja for the Jacobian --------------
         for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
         wave_sync();
@@ -242,6 +276,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             gnew[r] = (e < nq && ((mbits >> r) & 1u)) ? gg[e] : 0.0f;
         }
 
+        PROF_TICK(3);  // gradient
         // ---- accept / reject, stopping test --------------------------------------------------------------------------------
         bool ending = false, need_system = false;
         if (st_in != LM_DONE) {
@@ -284,45 +319,41 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             }
         }
 
+        PROF_TICK(4);  // accept + residual
         // ---- Gauss-Newton system of the accepted point ----------------------------------------------------------------------
         const int n = kh.nd;
         if (__any(need_system)) {
             if (need_system) {
+                auto geom = [&](int d) {
+                    const int4 dr = *reinterpret_cast<const int4 *>(KT + kh.off_dof + 4 * d);
+                    const float *jr = jrec + 12 * dr.y;
+                    DofGeom g2;
+                    g2.ty = reinterpret_cast<const int *>(jr)[0];
+                    g2.comp = dr.z;
+                    g2.anchor = ld3(ja + 7 * dr.y);
+                    g2.axis = ld3(ja + 7 * dr.y + 3);
+                    g2.qh = Q4{1.f, 0.f, 0.f, 0.f};
+                    g2.dn = 1.0f;
+                    if (g2.ty == JFREE) {
+                        const int ad = reinterpret_cast<const int *>(jr)[1];
+                        g2.qh = ld4(qe + ad + 3);
+                        const float nn = jn[dr.y];
+                        g2.dn = nn + (nn == 0.0f ? 1e-6f : 0.0f);
+                    }
+                    return g2;
+                };
                 // weighted Jacobian blocks of every (site, dof on its root path)
                 for (int it = lg; it < kh.ni; it += G) {
                     const int4 rec = *reinterpret_cast<const int4 *>(L.tab + kh.off_item + 4 * it);
-                    const int4 dr = *reinterpret_cast<const int4 *>(L.tab + kh.off_dof + 4 * rec.y);
-                    const int j = dr.y, comp = dr.z;
-                    const float *jr = jrec + 12 * j;
-                    const int ty = reinterpret_cast<const int *>(jr)[0];
-                    const V3 d = sub3(ld3(sxs + 3 * rec.x), ld3(ja + 7 * j));
-                    V3 col;
-                    if (ty == JHINGE) col = cross3(ld3(ja + 7 * j + 3), d);
-                    else if (ty == JSLIDE) col = ld3(ja + 7 * j + 3);
-                    else if (comp < 3) col = {comp == 0 ? 1.f : 0.f, comp == 1 ? 1.f : 0.f, comp == 2 ? 1.f : 0.f};
-                    else {
-                        const int ad = reinterpret_cast<const int *>(jr)[1];
-                        const Q4 qh = ld4(qe + ad + 3);
-                        const V3 u = {qh.x, qh.y, qh.z};
-                        const float nn = jn[j];
-                        const float dn = nn + (nn == 0.0f ? 1e-6f : 0.0f);
-                        if (comp == 3) {
-                            const V3 c = cross3(u, d);
-                            col = {(-2.0f * c.x) / dn, (-2.0f * c.y) / dn, (-2.0f * c.z) / dn};
-                        } else {
-                            const V3 e = {comp == 4 ? 1.f : 0.f, comp == 5 ? 1.f : 0.f, comp == 6 ? 1.f : 0.f};
-                            const V3 exd = cross3(e, d), t2 = cross3(cross3(e, u), d);
-                            col = {(2.0f * (qh.w * exd.x - t2.x)) / dn, (2.0f * (qh.w * exd.y - t2.y)) / dn,
-                                   (2.0f * (qh.w * exd.z - t2.z)) / dn};
-                        }
-                    }
+                    const V3 col = jac_col(geom(rec.y), ld3(sxs + 3 * rec.x));
                     // site weight (0/1): trunk mask in the root passes, all ones otherwise
                     const float w = trunk_w ? (a.kpw_sorted[rec.x] ? 1.f : 0.f) : 1.0f;
                     st3(Jp + (rec.x * kh.maxpd + rec.z) * 3, V3{col.x * w, col.y * w, col.z * w});
                 }
-                for (int i = lg; i < L.npk; i += G) Ap[i] = 0.0f;
+                for (int i = lg; i < kh.nd * kh.maxpd; i += G) Ap[i] = 0.0f;
             }
             wave_sync();
+            PROF_TICK(5);  // Jacobian blocks
             if (need_system) {
                 for (int en = lg; en < kh.ne; en += G) {
                     const int4 rec = *reinterpret_cast<const int4 *>(L.tab + kh.off_ent + 4 * en);
@@ -330,10 +361,10 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                     float s = 0.0f;
                     for (int i = lo; i < hi; ++i)
                         s += dot3(ld3(Jp + (i * kh.maxpd + pr) * 3), ld3(Jp + (i * kh.maxpd + pc) * 3));
-                    Ap[pk(rec.x, rec.y)] = s;
+                    Ap[rec.x * kh.maxpd + pc] = s;
                 }
                 for (int d = lg; d < n; d += G) {
-                    const int e = L.tab[kh.off_dof + 4 * d];
+                    const int e = KT[kh.off_dof + 4 * d];
                     const float b = -0.5f * gg[e];
                     bv[d] = b;
                     const float xe = qe[e];  // the accepted point (root quaternion normalised: never at +-1 unless axis-aligned)
@@ -345,64 +376,88 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                 // gauge: the length of the raw root quaternion does not change the pose -- make that direction stiff
                 int c = 0, e = lg;
                 while (e > c) { e -= c + 1; ++c; }  // lg -> (c, e), e <= c < 4
-                const int ad = L.tab[kh.off_dof + 4 * kh.quat0];
-                Ap[pk(kh.quat0 + c, kh.quat0 + e)] += qe[ad + c] * qe[ad + e];
+                // the four raw-quaternion dofs are consecutive on one root path: pd(quat0 + c) = pd(quat0) + c
+                const int ad = KT[kh.off_dof + 4 * kh.quat0], pd0 = KT[kh.off_dof + 4 * kh.quat0 + 3];
+                Ap[(kh.quat0 + c) * kh.maxpd + pd0 + e] += qe[ad + c] * qe[ad + e];
             }
             wave_sync();
         }
 
-        // ---- damped, bound-aware system -> Cholesky -> step -> trial point ---------------------------------------------------
+        PROF_TICK(6);  // J^T J entries, b, gauge
+        // ---- damped, bound-aware system -> L^T D L factorisation -> step -> trial point -------------------------------------
+        // J^T J of a kinematic tree is non-zero only between dofs on a common root path.  Rows hold their own
+        // path (row b, column pd(a)); eliminating the dofs leaves-first (Featherstone's L^T D L) creates no
+        // fill-in: dof k only touches the rows of its ancestors.
         const bool solving = (st_in != LM_DONE) && !ending;
+        const int mp = kh.maxpd;
+        bool bad = false;
         if (__any(solving)) {
             if (solving) {
-                for (int i = lg; i < n; i += G) {
-                    const bool fi = fz[i] != 0.0f;
-                    for (int j = 0; j <= i; ++j) {
-                        float v = Ap[pk(i, j)];
-                        if (fi || fz[j] != 0.0f) v = 0.0f;
-                        if (j == i) v = fi ? 1.0f : FMA(v, lam, v) + 1e-9f;
-                        Hc[pk(i, j)] = v;
-                    }
+                for (int en = lg; en < kh.ne; en += G) {
+                    const int4 rec = *reinterpret_cast<const int4 *>(L.tab + kh.off_ent + 4 * en);
+                    const int pc = rec.z >> 8;
+                    float v = Ap[rec.x * mp + pc];
+                    const bool fr = fz[rec.x] != 0.0f, fc = fz[rec.y] != 0.0f;
+                    if (rec.x == rec.y) v = fr ? 1.0f : FMA(v, lam, v) + 1e-9f;
+                    else if (fr || fc) v = 0.0f;
+                    Hc[rec.x * mp + pc] = v;
                 }
-            }
-            wave_sync();
-            // left-looking Cholesky, column by column; every lane recomputes the pivot (broadcast reads).
-            // Groups of one wave may have different n (different solve kinds): wave_sync is a fence, not a barrier.
-            bool bad = false;
-            if (solving) {
-                for (int j = 0; j < n; ++j) {
-                    float s = Hc[pk(j, j)];
-                    for (int k = 0; k < j; ++k) { const float v = Hc[pk(j, k)]; s = FMA(-v, v, s); }
-                    if (!(s > 0.0f)) { bad = true; s = 1.0f; }
-                    const float ljj = __builtin_sqrtf(s);
-                    for (int i = j + 1 + lg; i < n; i += G) {
-                        float t = Hc[pk(i, j)];
-                        for (int k = 0; k < j; ++k) t = FMA(-Hc[pk(i, k)], Hc[pk(j, k)], t);
-                        Hc[pk(i, j)] = t / ljj;
-                    }
-                    wave_sync();
-                    if (lg == 0) Hc[pk(j, j)] = ljj;
-                    wave_sync();
-                }
-                // forward substitution L y = b (column oriented), then backward L^T d = y
                 for (int i = lg; i < n; i += G) dv[i] = fz[i] != 0.0f ? 0.0f : bv[i];
-                wave_sync();
-                for (int k = 0; k < n; ++k) {
-                    const float yk = dv[k] / Hc[pk(k, k)];
+            }
+            wave_sync();
+            PROF_TICK(7);  // damped matrix
+            if (solving) {
+                const int *anc = KT + kh.off_anc;
+                for (int k = n - 1; k >= 0; --k) {
+                    const int pdk = KT[kh.off_dof + 4 * k + 3];
+                    const float *Hk = Hc + k * mp;
+                    const float dkk = Hk[pdk];
+                    if (!(dkk > 0.0f)) bad = true;
+                    // a_p = H[k][p] / H[k][k] for the ancestors p < pd(k); pairs (p_i >= p_j): H[anc_i][p_j] -= a_i H[k][p_j]
+                    const int T = (pdk * (pdk + 1)) >> 1;
+                    for (int q = lg; q < T; q += G) {
+                        const int pij = TRI[q], pi = pij >> 8, pj = pij & 0xFF;
+                        const int ai = anc[k * mp + pi];
+                        const float av = Hk[pi] / dkk;
+                        Hc[ai * mp + pj] = FMA(-av, Hk[pj], Hc[ai * mp + pj]);
+                    }
                     wave_sync();
-                    if (lg == 0) dv[k] = yk;
-                    for (int i = k + 1 + lg; i < n; i += G) dv[i] = FMA(-Hc[pk(i, k)], yk, dv[i]);
+                    for (int p = lg; p < pdk; p += G) Hc[k * mp + p] = Hk[p] / dkk;  // L[k][p]
+                    // y = L^-T b: b[anc] -= L[k][anc] b[k]
+                    wave_sync();
+                    const float bk = dv[k];
+                    for (int p = lg; p < pdk; p += G) { const int ai = anc[k * mp + p]; dv[ai] = FMA(-Hc[k * mp + p], bk, dv[ai]); }
                     wave_sync();
                 }
-                for (int i = n - 1; i >= 0; --i) {
-                    const float di = dv[i] / Hc[pk(i, i)];
+                PROF_TICK(8);  // L^T D L + backward pass
+                // z = D^-1 y, then d = L^-1 z.  A dof only depends on the dofs of its own root path: every lane
+                // keeps the running value of its dofs in registers; depth by depth the finished dofs are published
+                // and the deeper ones subtract L[i][depth] * d[ancestor at that depth].
+                constexpr int NDL = (192 + G - 1) / G;
+                float tv[NDL];
+                int pdv[NDL];
+#pragma unroll
+                for (int r = 0; r < NDL; ++r) {
+                    const int i = r * G + lg;
+                    pdv[r] = i < n ? KT[kh.off_dof + 4 * i + 3] : -1;
+                    tv[r] = i < n ? dv[i] / Hc[i * mp + pdv[r]] : 0.0f;
+                }
+                wave_sync();
+                for (int lev = 0; lev < mp; ++lev) {
+#pragma unroll
+                    for (int r = 0; r < NDL; ++r)
+                        if (pdv[r] == lev) dv[r * G + lg] = tv[r];
                     wave_sync();
-                    if (lg == 0) dv[i] = di;
-                    for (int k = lg; k < i; k += G) dv[k] = FMA(-Hc[pk(i, k)], di, dv[k]);
+#pragma unroll
+                    for (int r = 0; r < NDL; ++r) {
+                        const int i = r * G + lg;
+                        if (pdv[r] > lev) tv[r] = FMA(-Hc[i * mp + lev], dv[anc[i * mp + lev]], tv[r]);
+                    }
                     wave_sync();
                 }
             }
             wave_sync();
+            PROF_TICK(9);  // forward pass
             if (solving) {
                 if (bad) {  // not positive definite at this damping: treat as a rejected step
                     lam = lam * 4.0f;
@@ -415,7 +470,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             }
             wave_sync();
             if (solving && !bad)
-                for (int d = lg; d < n; d += G) gg[L.tab[kh.off_dof + 4 * d]] = dv[d];
+                for (int d = lg; d < n; d += G) gg[KT[kh.off_dof + 4 * d]] = dv[d];
             wave_sync();
             if (solving && !bad) {
 #pragma unroll
@@ -428,6 +483,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             wave_sync();
         }
 
+        PROF_TICK(10);  // trial point
         // ---- end of a solve: replace_qs, next solve / next frame (same sequencing as the PG kernel) ----------------------------
         if (__any(ending)) {
             if (ending) {
@@ -496,7 +552,9 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             }
             wave_sync();
         }
+        PROF_TICK(11);  // end of solve
     }
+    PROF_FLUSH(a);
 }
 
 template <int G, int NQR>

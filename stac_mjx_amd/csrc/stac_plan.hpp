@@ -103,30 +103,35 @@ struct QArgs {
 };
 
 // ---- optional LM solver (stac_lm.hip): per solve-kind tables in one global-memory blob of 32-bit words -----
-struct LmKind {            // 8 words, at blob[kind * 8]
-    int32_t nd;            // optimised coordinates with structural support ("dofs"), in qpos order
+struct LmKind {            // 12 words, at blob[kind * 12]
+    int32_t nd;            // optimised coordinates with structural support ("dofs"), ancestors first
     int32_t ne;            // structurally non-zero entries (row >= col) of J^T J
     int32_t ni;            // (site, dof) pairs with a non-zero Jacobian block
-    int32_t maxpd;         // longest root path, counted in dofs
-    int32_t off_dof;       // LmDof[nd]
-    int32_t off_ent;       // LmEnt[ne], longest site range first
-    int32_t off_item;      // LmItem[ni]
+    int32_t maxpd;         // longest root path, counted in dofs (= row stride of the path-compressed matrices)
+    int32_t off_dof;       // LmDof[nd]            -- offset inside the HOT section (staged in LDS)
+    int32_t off_ent;       // LmEnt[ne], longest site range first   -- absolute, read from global memory
+    int32_t off_item;      // LmItem[ni]                            -- absolute, read from global memory
     int32_t quat0;         // index of the first raw root-quaternion dof when all four are optimised, else -1
+    int32_t off_anc;       // int32[nd * maxpd]: dof index at every position of the dof's root path (-1 beyond);
+                           // offset inside the HOT section
+    int32_t pad0, pad1, pad2;
 };
+constexpr int kLmKindWords = 12;
 struct LmDof { int32_t qadr, joint, comp, pd; };                 // qpos index, active joint, component, path depth
 struct LmEnt { int32_t row, col, pds, range; };                  // pds = pd_row | pd_col << 8; range = lo | hi << 16
 struct LmItem { int32_t sitepos, dof, pd, pad; };
 struct LmArgs {
-    const int32_t *tab;    // device blob: LmKind[nkinds] then the records
+    const int32_t *tab;    // device blob: LmKind[nkinds], HOT section (dof + path tables of every kind), then the rest
     int32_t nkinds;
+    int32_t hot_off, hot_words;  // the part every workgroup stages in LDS (it is walked in dependent loops)
     int32_t n_max;         // max nd over kinds
-    int32_t npk;           // n_max (n_max + 1) / 2 rounded up to a multiple of 4
+    int32_t npk;           // max over kinds of nd * maxpd (path-compressed matrix), rounded up to a multiple of 4
     int32_t maxpd;         // max over kinds
     float lambda0;
     // extra per-chain LDS regions (float offsets inside the chain region, after the PG layout)
     int32_t c_sx;          // [3K] site world positions by sorted-site position
-    int32_t c_jp;          // [K * maxpd * 3] weighted Jacobian blocks; aliased by the Cholesky factor H[npk]
-    int32_t c_A;           // [npk] packed lower triangle of J^T W J (+ gauge term)
+    int32_t c_jp;          // [K * maxpd * 3] weighted Jacobian blocks; aliased by the factor H[npk]
+    int32_t c_A;           // [npk] J^T W J (+ gauge term), row b holds its root-path columns: A[b * maxpd + pd(a)]
     int32_t c_b;           // [n_max] J^T W (kp - x)
     int32_t c_d;           // [n_max] step
     int32_t c_fz;          // [n_max] 1.0 where the coordinate is frozen at a bound
