@@ -20,6 +20,7 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
                           int *capacity_out);
 hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
                              int *capacity_out);
+int lm_waves_per_simd(int G, int nq);
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s);
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
@@ -620,12 +621,14 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
                                                    ((((L.maxpd * (L.maxpd + 1)) >> 1) + 3) & ~3);
         auto lds_for = [&](int wpb) { return (size_t)(((m->h.total_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
         int wpb = 0, best_waves = 0;
-        for (int w = 1; w <= 4; ++w) {
+        const int wps = lm_waves_per_simd(G, m->h.nq);
+        for (int w = 1; w <= 8; ++w) {
             size_t lds = lds_for(w);
             if (lds > kLdsPerCu) break;
             lds = (lds + 1279) / 1280 * 1280;
             int blocks = (int)(kLdsPerCu / lds);
-            if (blocks * w > 8) blocks = 8 / w;
+            if (w <= 4) { if (blocks * w > 4 * wps) blocks = 4 * wps / w; }
+            else { const int per_simd = (w + 3) / 4; if (blocks * per_simd > wps) blocks = wps / per_simd; }
             if (blocks * w > best_waves) { best_waves = blocks * w; wpb = w; }
         }
         if (!wpb) continue;

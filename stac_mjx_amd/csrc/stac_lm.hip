@@ -45,8 +45,8 @@ __device__ __forceinline__ V3 jac_col(const DofGeom &g, V3 sx) {
             (2.0f * (g.qh.w * exd.z - t2.z)) / g.dn};
 }
 
-template <int G, int NQR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int G, int NQR, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
@@ -557,32 +557,35 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     PROF_FLUSH(a);
 }
 
-template <int G, int NQR>
+template <int G, int NQR, int WPE>
 static hipError_t launch_lm(const QArgs &a, const LmArgs &L, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = 64 / G;
     const int per_block = CPW * wpb;
     const int blocks = (a.C + per_block - 1) / per_block;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_lm_kernel<G, NQR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_lm_kernel<G, NQR, WPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((q_phase_lm_kernel<G, NQR>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a, L);
+    hipLaunchKernelGGL((q_phase_lm_kernel<G, NQR, WPE>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a, L);
     return hipGetLastError();
 }
 
+// Register caps: the 64-lane instantiations fit 168 VGPRs (3 waves per SIMD), the narrower ones need 2 per SIMD.
 hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
                              int *capacity_out) {
     const int nq = a.h.nq;
     *capacity_out = 0;
-#define STAC_TRY(GG, RR)                                    \
-    if (G == GG && nq <= GG * RR) {                         \
-        *capacity_out = GG * RR;                            \
-        return launch_lm<GG, RR>(a, L, wpb, lds_bytes, s);  \
+#define STAC_TRY(GG, RR, WW)                                    \
+    if (G == GG && nq <= GG * RR) {                             \
+        *capacity_out = GG * RR;                                \
+        return launch_lm<GG, RR, WW>(a, L, wpb, lds_bytes, s);  \
     }
-    STAC_TRY(16, 5) STAC_TRY(16, 8) STAC_TRY(16, 16)
-    STAC_TRY(32, 3) STAC_TRY(32, 8)
-    STAC_TRY(64, 2) STAC_TRY(64, 4)
+    STAC_TRY(16, 5, 2) STAC_TRY(16, 8, 2) STAC_TRY(16, 16, 2)
+    STAC_TRY(32, 3, 2) STAC_TRY(32, 8, 2)
+    STAC_TRY(64, 2, 3) STAC_TRY(64, 4, 2)
 #undef STAC_TRY
     return hipErrorInvalidValue;
 }
+
+int lm_waves_per_simd(int G, int nq) { return (G == 64 && nq <= 128) ? 3 : 2; }
 
 }  // namespace stac

@@ -38,8 +38,12 @@ class Stac:
         self._body_names = s.tables.body_names
         self._freejoint, self._slidejoint, self._fixed = s.freejoint, s.slidejoint, s.fixed_root
         stac_cfg = cfg.stac
+        # `stac.solver` is an engine extension of the config surface: "pg" (default) = the reference's projected
+        # gradient, reproduced exactly; "lm" = optional Levenberg-Marquardt solver (faster, fits the markers at
+        # least as well, but does not reproduce the reference's truncated iterates).
         self.engine = Engine(s.tables, s.lb, s.ub, tol=float(cfg.model.FTOL), maxiter=int(cfg.model.N_ITER_Q),
-                             lanes_per_chain=int(stac_cfg.get("lanes_per_chain", 0) or 0), device=device)
+                             lanes_per_chain=int(stac_cfg.get("lanes_per_chain", 0) or 0), device=device,
+                             solver=str(stac_cfg.get("solver", "pg") or "pg"))
         self.stac_core_obj = StacCore(self.engine, float(cfg.model.FTOL), int(cfg.model.N_ITER_Q))
         self._offsets = torch.as_tensor(s.tables.site_pos.copy())
         self._timestep = s.tables.timestep

@@ -127,3 +127,23 @@ def test_run_stac_end_to_end(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
     cfg2 = _cfg(rodent_cfg, n_fit_frames=4, skip_ik_only=True)
     cfg2.model.N_ITERS = 1
     assert run_stac(cfg2, kp, rodent_setup.kp_names, base_path=tmp_path, setup=rodent_setup)[1] is None
+
+
+def test_lm_solver_through_the_config_surface(rodent_setup, rodent_cfg, rodent_mocap):
+    """`stac.solver: lm` (engine extension): same API and outputs, better or equal marker fit than PG, far fewer
+    iterations; offsets are fitted with the same closed form."""
+    from stac_mjx_amd.stac import Stac
+
+    kp = rodent_mocap[:40]
+    out = {}
+    for solver in ("pg", "lm"):
+        cfg = _cfg(rodent_cfg, n_frames_per_clip=1, solver=solver)
+        cfg.model.N_ITERS = 1
+        stac = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False)
+        fit = stac.fit_offsets(kp[:10])
+        ik = stac.ik_only(kp, fit.offsets)
+        err = np.linalg.norm(ik.marker_sites - kp.reshape(40, 23, 3), axis=-1).mean()
+        out[solver] = (fit, ik, err)
+    assert out["lm"][1].qpos.shape == (40, 74) and np.isfinite(out["lm"][1].qpos).all()
+    assert out["lm"][2] <= out["pg"][2] + 2e-4, (out["lm"][2], out["pg"][2])
+    assert np.abs(out["lm"][0].offsets - out["pg"][0].offsets).max() < 2e-2  # same calibration up to solver differences
