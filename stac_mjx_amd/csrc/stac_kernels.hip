@@ -11,17 +11,17 @@
 //                    outputs of pose_optimization (compute_stac.py:261-264).
 //   m_* kernels      the cross-frame sums and closed form of _m_opt (stac_core.py:102-172).
 //
-// Execution model: a workgroup is ONE 64-lane wavefront.  A wavefront is split into 64/G groups of
-// G lanes; each group owns one chain (clip) and cooperates on it: lanes of a group take the bodies
+// Execution model: a workgroup holds 1-8 independent 64-lane wavefronts that only share one LDS copy of
+// the model plan.  A wavefront is split into 64/G groups of G lanes; each group owns one chain (clip) and cooperates on it: lanes of a group take the bodies
 // of one tree level, the marker sites, the joints, and 1/G of every nq-vector (held in registers).
 // The model "plan" (active subtree tables) and the per-chain transforms live in LDS.  Every group
 // runs its own solver state machine, so chains of one wavefront may be in different solves, line
 // searches or frames: each trip round the main loop is one q_loss evaluation for every group.
 //
 // Arithmetic contract: every float operation sequence here is the one of oracle/stac_oracle.c
-// (same expression trees, same summation orders, no FMA contraction: build with
-// -ffp-contract=off), so results are bit-identical to the CPU oracle; tests/test_gpu_parity.py
-// checks exactly that.  There is no dense contraction on this path, hence no MFMA.
+// (same expression trees with the same explicit fma placement, same summation orders; build with
+// -ffp-contract=off so nothing else is contracted), so results are bit-identical to the CPU oracle;
+// tests/test_gpu_parity.py checks exactly that.  There is no dense contraction on this path, hence no MFMA.
 #include <hip/hip_runtime.h>
 
 #include "stac_plan.hpp"

@@ -77,14 +77,14 @@ struct FullModel {
 };
 
 struct QArgs {
-    const PlanHeader *hdr;  // device copy of the header
+    const PlanHeader *hdr;  // unused (reserved)
     const float *plan;      // device blob
     PlanHeader h;           // by-value copy (kernel argument, scalar registers)
     // problem
     const float *kp;        // [C,F,3K]
     const float *q_init;    // [C,nq] or null
     const uint8_t *masks;   // device [nkinds, nqpad] bytes: kind 0,1 = root passes, 2 = full, 3.. = parts
-    const uint8_t *kpw;     // device [2, K] bytes: row 0 = trunk mask (root passes), row 1 = all ones / single-solve mask
+    const uint8_t *kpw;     // device [K] bytes: trunk mask (weights of the root passes)
     const uint8_t *kpw3;    // device [3K] per-coordinate mask for single-solve mode (or null)
     const uint8_t *kpw_sorted;  // device [K] trunk mask by sorted-site position (LM solver)
     int32_t C, F, P;
