@@ -122,10 +122,36 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         if (sb < 0 || sb >= nb) return fail(STAC_ERR_INVALID, "site_bodyid out of range");
         for (int b = sb; b > 0 && !active[b]; b = t->body_parentid[b]) active[b] = 1;
     }
-    std::vector<int> slots;  // body ids sorted by (depth, id)
+    // Active bodies level by level.  Inside a level a body takes its parent's position wherever that position
+    // exists in its own level (the kernel lane that finished the parent then continues with the child and
+    // keeps the transform in registers); the deepest subtrees choose first, so long limbs stay on one lane.
+    std::vector<int> height(nb, 0);
+    for (int b = nb - 1; b >= 1; --b)
+        if (active[b]) height[t->body_parentid[b]] = std::max(height[t->body_parentid[b]], height[b] + 1);
+    int max_depth_active = 0;
     for (int b = 1; b < nb; ++b)
-        if (active[b]) slots.push_back(b);
-    std::stable_sort(slots.begin(), slots.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+        if (active[b]) max_depth_active = std::max(max_depth_active, depth[b]);
+    std::vector<int> slots, pos_in_level(nb, -1);
+    for (int d = 1; d <= max_depth_active; ++d) {
+        std::vector<int> bodies;
+        for (int b = 1; b < nb; ++b)
+            if (active[b] && depth[b] == d) bodies.push_back(b);
+        std::stable_sort(bodies.begin(), bodies.end(), [&](int a, int b) { return height[a] > height[b]; });
+        const int w = (int)bodies.size();
+        std::vector<int> at(w, -1);
+        std::vector<char> placed(w, 0);
+        for (int i = 0; i < w; ++i) {  // deepest first: inherit the parent's position if it is free
+            const int pp = pos_in_level[t->body_parentid[bodies[i]]];
+            if (pp >= 0 && pp < w && at[pp] < 0) { at[pp] = bodies[i]; placed[i] = 1; }
+        }
+        int free_pos = 0;
+        for (int i = 0; i < w; ++i) {
+            if (placed[i]) continue;
+            while (at[free_pos] >= 0) ++free_pos;
+            at[free_pos] = bodies[i];
+        }
+        for (int i = 0; i < w; ++i) { pos_in_level[at[i]] = i; slots.push_back(at[i]); }
+    }
     const int nab = (int)slots.size();
     if (nab == 0) return fail(STAC_ERR_INVALID, "all fit sites are attached to the world body");
     std::vector<int> slot_of(nb, -1);
@@ -188,6 +214,8 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.nqpad = (nq + 3) & ~3;
     h.has_ball = has_ball;
     m->max_depth = nlev;
+    h.max_width = 0;
+    for (int l = 0; l < nlev; ++l) h.max_width = std::max(h.max_width, lev_adr[l + 1] - lev_adr[l]);
     m->h_ab_parent = ab_parent; m->h_aj_type = aj_type; m->h_aj_qadr = aj_qadr; m->h_aj_slot = aj_slot;
     m->h_aj_slo = aj_slo; m->h_aj_shi = aj_shi; m->h_sortpos = sortpos;
     if (nab >= 65535 || K >= 65535) return fail(STAC_ERR_CAPACITY, "too many bodies / sites");
@@ -215,8 +243,14 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         r.parent = ab_parent[s]; r.jadr = ab_jadr[s]; r.jnum = ab_jnum[s];
         const float *q = t->body_quat + 4 * b;
         r.flags = (q[0] == 1.0f && q[1] == 0.0f && q[2] == 0.0f && q[3] == 0.0f) ? 1 : 0;
+        const int pb = t->body_parentid[b];
+        if (pb > 0 && pos_in_level[pb] == pos_in_level[b]) r.flags |= 2;  // parent transform is in the lane's registers
         for (int i = 0; i < 3; ++i) r.pos[i] = t->body_pos[3 * b + i];
-        r.pad = 0.f;
+        r.jzero = 0;
+        for (int jj = 0; jj < ab_jnum[s] && jj < 31; ++jj) {
+            const float *jp = aj_pos.data() + 3 * (ab_jadr[s] + jj);
+            if (jp[0] == 0.0f && jp[1] == 0.0f && jp[2] == 0.0f) r.jzero |= (1 << jj);
+        }
         for (int i = 0; i < 4; ++i) r.quat[i] = q[i];
     }
     std::vector<JointRec> jrec(std::max(naj, 1));
@@ -252,6 +286,8 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     o = (o + 3) & ~3;
     h.c_gg = o; o += std::max(h.nqpad, (K + 3) & ~3);
     o = (o + 3) & ~3;
+    h.c_ql = h.c_sw;  // joint-local quaternions [naj*4]: alive only until the site pass overwrites sw / gg
+    o = std::max(o, h.c_ql + naj * 4);
     h.c_qe = o; o += h.nqpad;
     h.c_kp = o; o += 3 * K;
     // odd stride (mod 32 banks) so that the chains of one wavefront hit different LDS banks
@@ -471,11 +507,11 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost);
-        static const char *names[] = {"loop", "stage", "fk", "sites", "loss_sum", "zero_gg", "joint_grad", "trans_sums", "accept_fused", "end_solve", "-", "-"};
+        static const char *names[] = {"loop", "stage", "fk", "sites", "loss_sum", "zero_gg", "joint_grad", "trans_sums", "accept_fused", "end_solve", "prepass", "-"};
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += h[i];
         fprintf(stderr, "[stac profile] G=%d", G);
-        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
         fprintf(stderr, " total_wave_cycles=%.3g\n", (double)tot);
     }
 #endif

@@ -72,7 +72,7 @@ void q_phase_kernel(const QArgs a) {
     float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn;
     float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
-    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
+    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp, *ql = CB + H.c_ql;
     __syncthreads();  // the only workgroup-wide barrier: the plan is shared by the block's waves
 
     const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
@@ -160,70 +160,103 @@ void q_phase_kernel(const QArgs a) {
         wave_sync();
         PROF_TICK(1);  // stage
 
-        // ---- forward kinematics, level by level (mjx smooth.kinematics; SURVEY.md A1) -------------
-        for (int lev = 0; lev < H.nlev; ++lev) {
-            const int s_end = lev_adr[lev + 1];
-            for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
-                const float *br = brec + 12 * s;
-                const int4 bi = lds4i(br);       // parent, jadr, jnum, flags
-                const float4 bp = lds4(br + 4);  // pos
-                const float *pp = bx + bi.x * 7;
-                const V3 ppos = ld3(pp);
-                const Q4 pquat = ld4(pp + 3);
-                V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
-                Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
-                if (!(bi.w & 1)) {
-                    const float4 bq = lds4(br + 8);
-                    quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
-                }
-                const int j1 = bi.y + bi.z;
-                for (int j = bi.y; j < j1; ++j) {
-                    const float *jr = jrec + 12 * j;
-                    const int4 ji = lds4i(jr);        // type, qadr, slo, shi
-                    const float4 jp4 = lds4(jr + 4);  // pos, q0
-                    const float4 ja4 = lds4(jr + 8);  // axis, slot
-                    const int ty = ji.x, ad = ji.y;
-                    const V3 jp = {jp4.x, jp4.y, jp4.z}, jax = {ja4.x, ja4.y, ja4.z};
-                    V3 anchor;
-                    const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
-                    if (ty == JHINGE) {
-                        anchor = add3(rotate(jp, quat), pos);
-                        const float angle = qe[ad] - jp4.w;
-                        float sn, cs;
-                        sincos_(angle * 0.5f, &sn, &cs);
-                        const Q4 qloc = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
-                        quat = qmul(quat, qloc);
-                        pos = sub3(anchor, rotate(jp, quat));
-                    } else if (ty == JFREE) {
-                        anchor = ld3(qe + ad);
-                        pos = anchor;
-                        float n;
-                        quat = normalize4(ld4(qe + ad + 3), &n);
-                        st4(qe + ad + 3, quat);  // written back, like MJX
-                        jn[j] = n;
-                    } else if (ty == JSLIDE) {
-                        anchor = add3(rotate(jp, quat), pos);
-                        const V3 axis = rotate(jax, quat);
-                        const float d = qe[ad] - jp4.w;
-                        pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
-                    } else {  // ball
-                        anchor = add3(rotate(jp, quat), pos);
-                        float n;
-                        const Q4 qloc = normalize4(ld4(qe + ad), &n);
-                        st4(qe + ad, qloc);
-                        jn[j] = n;
-                        quat = qmul(quat, qloc);
-                        pos = sub3(anchor, rotate(jp, quat));
-                    }
-                    if (any_grad) {
-                        st3(ja + 7 * j, anchor);
-                        st4(ja + 7 * j + 3, prequat);
-                    }
-                }
-                st3(bx + (s + 1) * 7, pos);
-                st4(bx + (s + 1) * 7 + 3, quat);
+        // ---- joint-local transforms: everything of the kinematics that depends on q alone, one lane per joint
+        //      (hinge: the half-angle sincos and the local quaternion; free / ball: the normalised quaternion,
+        //      written back like MJX does; slide: the displacement).  This keeps the sincos off the serial
+        //      level-by-level chain below.  ql aliases the site-wrench / gradient scratch, which is dead here.
+        for (int j = lg; j < H.naj; j += G) {
+            const float *jr = jrec + 12 * j;
+            const int4 ji = lds4i(jr);  // type, qadr, slo, shi
+            const int ty = ji.x, ad = ji.y;
+            if (ty == JHINGE) {
+                const float4 jp4 = lds4(jr + 4);  // pos, q0
+                const float4 ja4 = lds4(jr + 8);  // axis, slot
+                const float angle = qe[ad] - jp4.w;
+                float sn, cs;
+                sincos_(angle * 0.5f, &sn, &cs);
+                st4(ql + 4 * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
+            } else if (ty == JSLIDE) {
+                const float4 jp4 = lds4(jr + 4);
+                ql[4 * j] = qe[ad] - jp4.w;
+            } else {
+                const int qa = ty == JFREE ? ad + 3 : ad;
+                float n;
+                const Q4 qn = normalize4(ld4(qe + qa), &n);
+                st4(qe + qa, qn);  // written back, like MJX
+                st4(ql + 4 * j, qn);
+                jn[j] = n;
             }
-            wave_sync();
+        }
+        wave_sync();
+        PROF_TICK(10);  // joint-local pre-pass
+
+        // ---- forward kinematics, level by level (mjx smooth.kinematics; SURVEY.md A1) -------------
+        // A lane keeps the transform of the body it has just finished: the host lays the levels out so that a
+        // body sits at its parent's position in the level wherever it can (flag bit 1), and then the parent
+        // transform never makes the LDS round trip.
+        {
+            const bool carry_ok = H.max_width <= G;  // every level is a single pass
+            V3 cpos = {0.f, 0.f, 0.f};
+            Q4 cquat = {1.f, 0.f, 0.f, 0.f};
+            for (int lev = 0; lev < H.nlev; ++lev) {
+                const int s_end = lev_adr[lev + 1];
+                for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
+                    const float *br = brec + 12 * s;
+                    const int4 bi = lds4i(br);       // parent, jadr, jnum, flags
+                    const float4 bp = lds4(br + 4);  // pos, zero-jnt_pos bits
+                    V3 ppos = cpos;
+                    Q4 pquat = cquat;
+                    if (!(carry_ok && (bi.w & 2))) {
+                        const float *pp = bx + bi.x * 7;
+                        ppos = ld3(pp);
+                        pquat = ld4(pp + 3);
+                    }
+                    V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
+                    Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
+                    if (!(bi.w & 1)) {
+                        const float4 bq = lds4(br + 8);
+                        quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
+                    }
+                    const int jz = __builtin_bit_cast(int, bp.w);
+                    for (int jj = 0; jj < bi.z; ++jj) {
+                        const int j = bi.y + jj;
+                        const float *jr = jrec + 12 * j;
+                        const int4 ji = lds4i(jr);        // type, qadr, slo, shi
+                        const float4 jp4 = lds4(jr + 4);  // pos, q0
+                        const int ty = ji.x, ad = ji.y;
+                        const V3 jp = {jp4.x, jp4.y, jp4.z};
+                        // jnt_pos == 0: rotate(0, q) is a zero vector, so anchor = pos and pos stays (exact)
+                        const bool jzero = jj < 31 && ((jz >> jj) & 1);
+                        const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+                        V3 anchor = pos;
+                        if (ty == JHINGE || ty == JBALL) {
+                            const Q4 qloc = ld4(ql + 4 * j);
+                            if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                            quat = qmul(quat, qloc);
+                            if (!jzero) pos = sub3(anchor, rotate(jp, quat));
+                        } else if (ty == JFREE) {
+                            anchor = ld3(qe + ad);
+                            pos = anchor;
+                            quat = ld4(qe + ad + 3);  // normalised by the pre-pass
+                        } else {  // slide
+                            if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                            const float4 ja4 = lds4(jr + 8);
+                            const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+                            const float d = ql[4 * j];
+                            pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+                        }
+                        if (any_grad) {
+                            st3(ja + 7 * j, anchor);
+                            st4(ja + 7 * j + 3, prequat);
+                        }
+                    }
+                    st3(bx + (s + 1) * 7, pos);
+                    st4(bx + (s + 1) * 7 + 3, quat);
+                    cpos = pos;
+                    cquat = quat;
+                }
+                wave_sync();
+            }
         }
 
         PROF_TICK(2);  // FK
@@ -307,7 +340,15 @@ void q_phase_kernel(const QArgs a) {
                 const int4 ji = lds4i(jr);  // type, qadr, slo, shi
                 const int ty = ji.x, ad = ji.y;
                 V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
-                for (int i = ji.z; i < ji.w; ++i) {
+                int i = ji.z;
+                for (; i + 4 <= ji.w; i += 4) {  // same left-to-right order; four wrenches in flight per LDS round trip
+                    V3 f4[4], t4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { f4[u] = ld3(sw + 6 * (i + u)); t4[u] = ld3(sw + 6 * (i + u) + 3); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { Fs = add3(Fs, f4[u]); T0 = add3(T0, t4[u]); }
+                }
+                for (; i < ji.w; ++i) {
                     Fs = add3(Fs, ld3(sw + 6 * i));
                     T0 = add3(T0, ld3(sw + 6 * i + 3));
                 }

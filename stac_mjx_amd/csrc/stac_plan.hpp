@@ -17,8 +17,10 @@ struct BodyRec {      // 12 words
     int32_t jadr;     // first joint record
     int32_t jnum;
     int32_t flags;    // bit 0: body_quat is the identity (product with it is exact, skipped)
+                      // bit 1: the parent sits at the same position of the previous level (its transform is still
+                      //        in the registers of the lane that now takes this body)
     float pos[3];
-    float pad;
+    int32_t jzero;    // bit i: joint i of the body has jnt_pos == 0 (rotate(0, q) = 0: anchor = pos, exact)
     float quat[4];
 };
 struct JointRec {     // 12 words
@@ -63,6 +65,8 @@ struct PlanHeader {
     int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place)
     int32_t c_kp;      // [3K] keypoints of the current frame
     int32_t chain_stride;
+    int32_t c_ql;      // [naj*4] joint-local quaternions of the evaluation point; aliases c_sw.. (dead during FK)
+    int32_t max_width; // bodies in the widest level
 };
 
 // Full-model tables for the stand-alone FK / offset-phase kernels (device pointers).
