@@ -274,6 +274,57 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.off_qpos0 = put_fpad(t->qpos0, nq, h.nqpad);
     quat_adr.push_back(0);
     h.off_quat_adr = put_raw(quat_adr.data(), quat_adr.size());
+    h.core_words = (int)B.size();  // what a kernel that walks the levels itself stages in LDS
+    {   // FK program (FkStep records, see stac_plan.hpp)
+        const int W = h.max_width;
+        bool any_bquat = false;
+        for (int s = 0; s < nab; ++s) any_bquat = any_bquat || !(brec[s].flags & 1);
+        const int rw = any_bquat ? 16 : 12;
+        std::vector<int> mfirst(nlev + 1, 0);
+        for (int l = 0; l < nlev; ++l) {
+            int mm = 1;
+            for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) mm = std::max(mm, ab_jnum[s]);
+            mfirst[l + 1] = mfirst[l] + mm;
+        }
+        const int n_mlev = mfirst[nlev];
+        std::vector<int32_t> prog((size_t)n_mlev * W * rw, 0);
+        auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+        for (int l = 0; l < nlev; ++l)
+            for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) {
+                const int pp = s - lev_adr[l], njs = ab_jnum[s], nsteps = std::max(1, njs);
+                for (int i = 0; i < nsteps; ++i) {
+                    int32_t *r = prog.data() + ((size_t)(mfirst[l] + i) * W + pp) * rw;
+                    int32_t fl = 0;
+                    if (i == 0) {
+                        fl |= FK_BODY;
+                        if (!(brec[s].flags & 2)) fl |= FK_PARENT_LDS;
+                        if (!(brec[s].flags & 1)) fl |= FK_BQUAT;
+                        r[1] = ab_parent[s];
+                        for (int c = 0; c < 3; ++c) r[4 + c] = f2i(brec[s].pos[c]);
+                        if (rw == 16) for (int c = 0; c < 4; ++c) r[12 + c] = f2i(brec[s].quat[c]);
+                    }
+                    if (i < njs) {
+                        const int j = ab_jadr[s] + i;
+                        fl |= FK_JOINT | (aj_type[j] << FK_JTYPE_SHIFT);
+                        if (aj_pos[3 * j] == 0.0f && aj_pos[3 * j + 1] == 0.0f && aj_pos[3 * j + 2] == 0.0f) fl |= FK_JZERO;
+                        r[2] = j;
+                        for (int c = 0; c < 3; ++c) r[8 + c] = f2i(aj_pos[3 * j + c]);
+                        r[11] = aj_qadr[j];
+                    }
+                    if (i == nsteps - 1) fl |= FK_LAST;
+                    r[0] = fl;
+                    r[7] = s + 1;
+                }
+            }
+        for (int ml = 0; ml + 1 < n_mlev; ++ml)
+            for (int pp = 0; pp < W; ++pp) {
+                const int32_t *nx = prog.data() + ((size_t)(ml + 1) * W + pp) * rw;
+                if (nx[0] & FK_JOINT) prog[((size_t)ml * W + pp) * rw + 3] = nx[2];
+            }
+        h.off_fkstep = put_raw(prog.data(), prog.size());
+        h.n_mlev = n_mlev;
+        h.fk_rec_words = rw;
+    }
     h.total_words = (int)B.size();
 
     // per-chain LDS layout
@@ -286,8 +337,6 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     o = (o + 3) & ~3;
     h.c_gg = o; o += std::max(h.nqpad, (K + 3) & ~3);
     o = (o + 3) & ~3;
-    h.c_ql = h.c_sw;  // joint-local quaternions [naj*4]: alive only until the site pass overwrites sw / gg
-    o = std::max(o, h.c_ql + naj * 4);
     h.c_qe = o; o += h.nqpad;
     h.c_kp = o; o += 3 * K;
     // odd stride (mod 32 banks) so that the chains of one wavefront hit different LDS banks
@@ -298,7 +347,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
 
 static int q_mb_words(int nkinds, int G) { return (nkinds * G + 3) & ~3; }
 static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
-    const int plan_words = (h.total_words + 3) & ~3;
+    const int plan_words = (h.total_words + 3) & ~3;  // h is the per-launch copy: total_words = what this launch stages
     return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * h.chain_stride) * sizeof(float);
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -486,18 +535,28 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         }
     }
     for (; !cap && G <= 64; G *= 2) {
-        QShape sh = pick_shape(m->h, G, nkinds, ((long)nchains * G + 63) / 64);
+        // The FK program (fixed-size step records, prefetched) costs LDS: stage it only if every level fits the
+        // lane group and the workgroups that fit a CU stay the same; else the kernel walks the levels itself.
+        const long waves_needed = ((long)nchains * G + 63) / 64;
+        a.h.total_words = m->h.core_words;
+        QShape sh = pick_shape(a.h, G, nkinds, waves_needed);
         if (!sh.wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
+        a.flags |= 2;
+        if (m->h.max_width <= G && !(getenv("STAC_HIP_FLAGS") && (atoi(getenv("STAC_HIP_FLAGS")) & 2))) {
+            PlanHeader hp = m->h;
+            const QShape shp = pick_shape(hp, G, nkinds, waves_needed);
+            if (shp.wpb && shp.waves_per_cu >= sh.waves_per_cu) { sh = shp; a.h.total_words = m->h.total_words; a.flags &= ~2; }
+        }
         if (const char *w = getenv("STAC_HIP_WPB")) {  // developer overrides
             const int ww = atoi(w);
-            if (ww >= 1 && ww <= 8 && q_lds_bytes(m->h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
+            if (ww >= 1 && ww <= 8 && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
         }
         if (const char *w = getenv("STAC_HIP_WPE")) sh.wpe = atoi(w) >= 4 ? 4 : 2;
         if (getenv("STAC_HIP_VERBOSE"))
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
-                    nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(m->h, G, nkinds, sh.wpb), m->h.chain_stride, m->h.total_words);
+                    nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), m->h.chain_stride, a.h.total_words);
         a.mb_words = q_mb_words(nkinds, G);
-        e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(m->h, G, nkinds, sh.wpb), s, &cap);
+        e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
         if (cap) break;  // an instantiation with this many lanes holds nq
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");
@@ -511,7 +570,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += h[i];
         fprintf(stderr, "[stac profile] G=%d", G);
-        for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
         fprintf(stderr, " total_wave_cycles=%.3g\n", (double)tot);
     }
 #endif
@@ -639,6 +698,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     a.hdr = nullptr;
     a.plan = m->d_blob;
     a.h = m->h;
+    a.h.total_words = m->h.core_words;  // the LM kernel walks the levels itself: no FK program in LDS
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const LmArgs &L = m->lm_args;
 #ifdef STAC_PROFILE
@@ -655,7 +715,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
         const int cpw = 64 / G;
         const int mbw = (2 * nkinds * G + 3) & ~3, khw = ((nkinds * kLmKindWords + 3) & ~3) + ((L.hot_words + 3) & ~3) +
                                                    ((((L.maxpd * (L.maxpd + 1)) >> 1) + 3) & ~3);
-        auto lds_for = [&](int wpb) { return (size_t)(((m->h.total_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
+        auto lds_for = [&](int wpb) { return (size_t)(((m->h.core_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
         int wpb = 0, best_waves = 0;
         const int wps = lm_waves_per_simd(G, m->h.nq);
         for (int w = 1; w <= 8; ++w) {

@@ -33,6 +33,180 @@ namespace stac {
 // q_phase kernel
 // ------------------------------------------------------------------------------------------------
 
+// Forward kinematics of one chain, level by level (mjx smooth.kinematics), by gf lanes (lf = this
+// lane's index among them): reads the evaluation point qe (quaternions already normalised) and the joint-local
+// quaternions ql, writes the body transforms bx and, if store_ja, every joint's anchor and pre-joint quaternion.
+// A lane keeps the transform of the body it has just finished: the host lays the levels out so that a body sits
+// at its parent's position in the level wherever it can (flag bit 1), and then the parent transform never makes
+// the LDS round trip.  All lanes of the wavefront must call it together (wave-level synchronisation per level).
+__device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                          const bool active, const bool store_ja) {
+    const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
+    const float *brec = P + H.off_body, *jrec = P + H.off_joint;
+    float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
+    const float *qe = CBc + H.c_qe, *qlb = CBc + H.c_ja + 3;
+    const bool carry_ok = H.max_width <= gf;  // every level is a single pass
+    V3 cpos = {0.f, 0.f, 0.f};
+    Q4 cquat = {1.f, 0.f, 0.f, 0.f};
+    for (int lev = 0; lev < H.nlev; ++lev) {
+        const int s_end = active ? lev_adr[lev + 1] : 0;
+        for (int s = lev_adr[lev] + lf; s < s_end; s += gf) {
+            const float *br = brec + 12 * s;
+            const int4 bi = lds4i(br);       // parent, jadr, jnum, flags
+            const float4 bp = lds4(br + 4);  // pos, zero-jnt_pos bits
+            V3 ppos = cpos;
+            Q4 pquat = cquat;
+            if (!(carry_ok && (bi.w & 2))) {
+                const float *pp = bx + bi.x * 7;
+                ppos = ld3(pp);
+                pquat = ld4(pp + 3);
+            }
+            V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
+            Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
+            if (!(bi.w & 1)) {
+                const float4 bq = lds4(br + 8);
+                quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
+            }
+            const int jz = __builtin_bit_cast(int, bp.w);
+            for (int jj = 0; jj < bi.z; ++jj) {
+                const int j = bi.y + jj;
+                const float *jr = jrec + 12 * j;
+                const int4 ji = lds4i(jr);        // type, qadr, slo, shi
+                const float4 jp4 = lds4(jr + 4);  // pos, q0
+                const int ty = ji.x, ad = ji.y;
+                const V3 jp = {jp4.x, jp4.y, jp4.z};
+                // jnt_pos == 0: rotate(0, q) is a zero vector, so anchor = pos and pos stays (exact)
+                const bool jzero = jj < 31 && ((jz >> jj) & 1);
+                const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+                V3 anchor = pos;
+                if (ty == JHINGE || ty == JBALL) {
+                    const Q4 qloc = ld4(qlb + 7 * j);
+                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                    quat = qmul(quat, qloc);
+                    if (!jzero) pos = sub3(anchor, rotate(jp, quat));
+                } else if (ty == JFREE) {
+                    anchor = ld3(qe + ad);
+                    pos = anchor;
+                    quat = ld4(qe + ad + 3);  // normalised by the pre-pass
+                } else {  // slide
+                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                    const float4 ja4 = lds4(jr + 8);
+                    const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+                    const float d = qlb[7 * j];
+                    pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+                }
+                if (store_ja) {
+                    st3(ja + 7 * j, anchor);
+                    st4(ja + 7 * j + 3, prequat);
+                }
+            }
+            st3(bx + (s + 1) * 7, pos);
+            st4(bx + (s + 1) * 7 + 3, quat);
+            cpos = pos;
+            cquat = quat;
+        }
+        wave_sync();
+    }
+}
+
+// The same kinematics driven by the FK "program" (FkStep records, stac_plan.hpp): one fixed-size record per
+// (micro-level, lane position), so the record and the joint-local quaternion of step k+1 are fetched while
+// step k computes and the serial chain holds no dependent LDS round trip except a parent transform that
+// another lane produced (branch points of the tree).  Requires max_width <= gf.  Bit-identical to fk_levels.
+template <int RW>
+__device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                           const bool active, const bool store_ja) {
+    const int W = H.max_width;
+    const bool on = active && lf < W;
+    const float *sp = P + H.off_fkstep + RW * (on ? lf : 0);
+    const float *jrec = P + H.off_joint;
+    float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
+    const float *qe = CBc + H.c_qe, *qlb = CBc + H.c_ja + 3;
+    V3 cpos = {0.f, 0.f, 0.f};
+    Q4 cquat = {1.f, 0.f, 0.f, 0.f};
+    int4 r0 = lds4i(sp);
+    float4 r1 = lds4(sp + 4), r2 = lds4(sp + 8), r3 = {1.f, 0.f, 0.f, 0.f};
+    if constexpr (RW == 16) r3 = lds4(sp + 12);
+    if (!on) r0.x = 0;
+    Q4 qn = ld4(qlb + 7 * r0.z);
+    const int stride = RW * W;
+    for (int ml = 0; ml < H.n_mlev; ++ml) {
+        // fetch the next step (the last iteration re-reads its own record: harmless)
+        const float *np = (ml + 1 < H.n_mlev) ? sp + stride : sp;
+        const int4 n0 = lds4i(np);
+        const float4 n1 = lds4(np + 4), n2 = lds4(np + 8);
+        float4 n3 = {1.f, 0.f, 0.f, 0.f};
+        if constexpr (RW == 16) n3 = lds4(np + 12);
+        const Q4 qnn = ld4(qlb + 7 * r0.w);
+        const int fl = r0.x;
+        if (fl) {
+            V3 pos = cpos;
+            Q4 quat = cquat;
+            if (fl & FK_BODY) {
+                if (fl & FK_PARENT_LDS) {
+                    const float *pp = bx + r0.y * 7;
+                    pos = ld3(pp);
+                    quat = ld4(pp + 3);
+                }
+                pos = add3(pos, rotate(V3{r1.x, r1.y, r1.z}, quat));
+                if constexpr (RW == 16) {
+                    if (fl & FK_BQUAT) quat = qmul(quat, Q4{r3.x, r3.y, r3.z, r3.w});  // identity: exact, skipped
+                }
+            }
+            if (fl & FK_JOINT) {
+                const int j = r0.z, ty = (fl >> FK_JTYPE_SHIFT) & 3;
+                const V3 jp = {r2.x, r2.y, r2.z};
+                const bool jzero = fl & FK_JZERO;  // rotate(0, q) is a zero vector: anchor = pos, pos stays (exact)
+                const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+                V3 anchor = pos;
+                if (ty == JHINGE || ty == JBALL) {
+                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                    quat = qmul(quat, qn);
+                    if (!jzero) pos = sub3(anchor, rotate(jp, quat));
+                } else if (ty == JFREE) {
+                    const int ad = __builtin_bit_cast(int, r2.w);
+                    anchor = ld3(qe + ad);
+                    pos = anchor;
+                    quat = qn;  // normalised by the pre-pass
+                } else {  // slide
+                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                    const float4 ja4 = lds4(jrec + 12 * j + 8);
+                    const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+                    const float d = qn.w;
+                    pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+                }
+                if (store_ja) {
+                    st3(ja + 7 * j, anchor);
+                    st4(ja + 7 * j + 3, prequat);
+                }
+            }
+            if (fl & FK_LAST) {
+                const int xf = __builtin_bit_cast(int, r1.w);
+                st3(bx + xf * 7, pos);
+                st4(bx + xf * 7 + 3, quat);
+            }
+            cpos = pos;
+            cquat = quat;
+        }
+        wave_sync();
+        sp = np;
+        r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+        if (!on) r0.x = 0;
+        qn = qnn;
+    }
+}
+
+// FK of one chain by gf lanes: the program when every level fits the lanes, else the level loop.
+__device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                         const bool active, const bool store_ja, const bool use_levels) {
+    if (H.max_width <= gf && !use_levels) {
+        if (H.fk_rec_words == 16) fk_program<16>(H, P, CBc, lf, gf, active, store_ja);
+        else fk_program<12>(H, P, CBc, lf, gf, active, store_ja);
+    } else {
+        fk_levels(H, P, CBc, lf, gf, active, store_ja);
+    }
+}
+
 // WPE = waves per SIMD the register allocation is capped for (2 -> 256 VGPRs, 4 -> 128 VGPRs): the host
 // picks the variant that lets all chains of a launch be resident at once.
 //
@@ -72,7 +246,7 @@ void q_phase_kernel(const QArgs a) {
     float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn;
     float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
-    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp, *ql = CB + H.c_ql;
+    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp, *qlb = CB + H.c_ja + 3;  // joint-local quaternion of joint j: qlb + 7 j (the slot its pre-joint quaternion takes later)
     __syncthreads();  // the only workgroup-wide barrier: the plan is shared by the block's waves
 
     const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
@@ -163,7 +337,8 @@ void q_phase_kernel(const QArgs a) {
         // ---- joint-local transforms: everything of the kinematics that depends on q alone, one lane per joint
         //      (hinge: the half-angle sincos and the local quaternion; free / ball: the normalised quaternion,
         //      written back like MJX does; slide: the displacement).  This keeps the sincos off the serial
-        //      level-by-level chain below.  ql aliases the site-wrench / gradient scratch, which is dead here.
+        //      level-by-level chain below.  The result sits in the ja slot that the joint's pre-joint quaternion takes
+        //      once FK has consumed it, so it needs no LDS of its own.
         for (int j = lg; j < H.naj; j += G) {
             const float *jr = jrec + 12 * j;
             const int4 ji = lds4i(jr);  // type, qadr, slo, shi
@@ -174,16 +349,16 @@ void q_phase_kernel(const QArgs a) {
                 const float angle = qe[ad] - jp4.w;
                 float sn, cs;
                 sincos_(angle * 0.5f, &sn, &cs);
-                st4(ql + 4 * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
+                st4(qlb + 7 * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
             } else if (ty == JSLIDE) {
                 const float4 jp4 = lds4(jr + 4);
-                ql[4 * j] = qe[ad] - jp4.w;
+                qlb[7 * j] = qe[ad] - jp4.w;
             } else {
                 const int qa = ty == JFREE ? ad + 3 : ad;
                 float n;
                 const Q4 qn = normalize4(ld4(qe + qa), &n);
                 st4(qe + qa, qn);  // written back, like MJX
-                st4(ql + 4 * j, qn);
+                st4(qlb + 7 * j, qn);
                 jn[j] = n;
             }
         }
@@ -191,73 +366,7 @@ void q_phase_kernel(const QArgs a) {
         PROF_TICK(10);  // joint-local pre-pass
 
         // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
-        // A lane keeps the transform of the body it has just finished: the host lays the levels out so that a
-        // body sits at its parent's position in the level wherever it can (flag bit 1), and then the parent
-        // transform never makes the LDS round trip.
-        {
-            const bool carry_ok = H.max_width <= G;  // every level is a single pass
-            V3 cpos = {0.f, 0.f, 0.f};
-            Q4 cquat = {1.f, 0.f, 0.f, 0.f};
-            for (int lev = 0; lev < H.nlev; ++lev) {
-                const int s_end = lev_adr[lev + 1];
-                for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
-                    const float *br = brec + 12 * s;
-                    const int4 bi = lds4i(br);       // parent, jadr, jnum, flags
-                    const float4 bp = lds4(br + 4);  // pos, zero-jnt_pos bits
-                    V3 ppos = cpos;
-                    Q4 pquat = cquat;
-                    if (!(carry_ok && (bi.w & 2))) {
-                        const float *pp = bx + bi.x * 7;
-                        ppos = ld3(pp);
-                        pquat = ld4(pp + 3);
-                    }
-                    V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
-                    Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
-                    if (!(bi.w & 1)) {
-                        const float4 bq = lds4(br + 8);
-                        quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
-                    }
-                    const int jz = __builtin_bit_cast(int, bp.w);
-                    for (int jj = 0; jj < bi.z; ++jj) {
-                        const int j = bi.y + jj;
-                        const float *jr = jrec + 12 * j;
-                        const int4 ji = lds4i(jr);        // type, qadr, slo, shi
-                        const float4 jp4 = lds4(jr + 4);  // pos, q0
-                        const int ty = ji.x, ad = ji.y;
-                        const V3 jp = {jp4.x, jp4.y, jp4.z};
-                        // jnt_pos == 0: rotate(0, q) is a zero vector, so anchor = pos and pos stays (exact)
-                        const bool jzero = jj < 31 && ((jz >> jj) & 1);
-                        const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
-                        V3 anchor = pos;
-                        if (ty == JHINGE || ty == JBALL) {
-                            const Q4 qloc = ld4(ql + 4 * j);
-                            if (!jzero) anchor = add3(rotate(jp, quat), pos);
-                            quat = qmul(quat, qloc);
-                            if (!jzero) pos = sub3(anchor, rotate(jp, quat));
-                        } else if (ty == JFREE) {
-                            anchor = ld3(qe + ad);
-                            pos = anchor;
-                            quat = ld4(qe + ad + 3);  // normalised by the pre-pass
-                        } else {  // slide
-                            if (!jzero) anchor = add3(rotate(jp, quat), pos);
-                            const float4 ja4 = lds4(jr + 8);
-                            const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
-                            const float d = ql[4 * j];
-                            pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
-                        }
-                        if (any_grad) {
-                            st3(ja + 7 * j, anchor);
-                            st4(ja + 7 * j + 3, prequat);
-                        }
-                    }
-                    st3(bx + (s + 1) * 7, pos);
-                    st4(bx + (s + 1) * 7 + 3, quat);
-                    cpos = pos;
-                    cquat = quat;
-                }
-                wave_sync();
-            }
-        }
+        fk_chain(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0);
 
         PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------

@@ -33,6 +33,31 @@ struct JointRec {     // 12 words
     float axis[3];
     int32_t slot;     // body slot
 };
+// One step of the FK "program": the work of one lane position in one micro-level.  A level of the tree takes
+// max(1, most joints of a body in it) micro-levels; a body's first step composes it with its parent and applies
+// its first joint, further joints are further steps.  Fixed-size records at (micro_level * max_width + position)
+// make every address a function of the loop counter, so the kernel fetches step k+1 while it computes step k.
+struct FkStep {       // 12 words (+4 when some active body has a non-identity body_quat)
+    int32_t flags;    // FK_* bits; 0 = nothing to do at this position
+    int32_t parent;   // transform index of the parent (0 = world, s+1 = slot s)            [FK_BODY]
+    int32_t j;        // active joint index                                                   [FK_JOINT]
+    int32_t jnext;    // joint index of this position's next step (its ql is fetched one step ahead), else 0
+    float bpos[3];    // body_pos                                                             [FK_BODY]
+    int32_t xf;       // transform index this body is stored at (slot + 1)
+    float jpos[3];    // jnt_pos                                                              [FK_JOINT]
+    int32_t qadr;     // qpos address                                                         [FK_JOINT]
+    // float bquat[4] follows when PlanHeader::fk_rec_words == 16
+};
+enum : int32_t {
+    FK_BODY = 1,         // compose with the parent: pos = ppos + rotate(body_pos, pquat), quat = pquat * body_quat
+    FK_PARENT_LDS = 2,   // parent transform comes from LDS (else it is still in the lane's registers)
+    FK_BQUAT = 4,        // body_quat is not the identity
+    FK_JOINT = 8,
+    FK_JTYPE_SHIFT = 4,  // bits 4-5: mjtJoint
+    FK_JZERO = 64,       // jnt_pos == 0: rotate(0, q) = 0, anchor = pos (exact)
+    FK_LAST = 128,       // last step of the body: store its transform
+};
+
 struct SiteRec {      // 4 words
     float pos[3];     // the marker offset -- mutable (stac_set_site_pos writes the blob)
     int32_t slot_sortpos;  // body slot | sorted position << 16
@@ -55,7 +80,8 @@ struct PlanHeader {
     int32_t off_ub;        // [nqpad] float
     int32_t off_qpos0;     // [nqpad] float
     int32_t off_quat_adr;  // [nquat] qpos address of every quaternion (free: adr+3, ball: adr)
-    int32_t total_words;
+    int32_t total_words;   // words a launch stages in LDS (the per-launch copy may stop at core_words)
+    int32_t core_words;    // blob without the FK program (the program is last)
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
     int32_t c_bx;      // [(nab+1)*7] pos(3) quat(4); entry 0 = world
     int32_t c_ja;      // [naj*7] anchor(3) + quaternion before the joint(4) (the joint pass rotates the axis)
@@ -65,8 +91,10 @@ struct PlanHeader {
     int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place)
     int32_t c_kp;      // [3K] keypoints of the current frame
     int32_t chain_stride;
-    int32_t c_ql;      // [naj*4] joint-local quaternions of the evaluation point; aliases c_sw.. (dead during FK)
     int32_t max_width; // bodies in the widest level
+    int32_t off_fkstep;    // FkStep[n_mlev * max_width] (word offset into the blob)
+    int32_t n_mlev;        // micro-levels of the FK program
+    int32_t fk_rec_words;  // 12, or 16 when the records carry body_quat
 };
 
 // Full-model tables for the stand-alone FK / offset-phase kernels (device pointers).
@@ -95,7 +123,7 @@ struct QArgs {
     int32_t root_kp_idx, do_root_opt;
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
     int32_t mb_words;       // LDS words reserved for the per-kind mask bit table (multiple of 4)
-    int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations (A/B switch)
+    int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program (A/B switches)
     float tol;
     int32_t maxiter, maxls;
     // outputs
