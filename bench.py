@@ -176,6 +176,29 @@ def main():
                      "algorithmic_bytes_per_launch": frames_step * bytes_frame,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": bytes_frame},
     }
+    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent":
+        # the north star words the q_phase as a Levenberg-Marquardt update; the reference runs projected gradient (the
+        # `value` above, parity mode).  The optional LM solver on the same resident batch, for the record -- never `value`.
+        lm = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), device=f"cuda:{local_rank}",
+                    solver="lm")
+        lm.set_site_pos(synth_offsets(fs))
+        lo = None
+        lev = []
+        for i in range(1 + args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lo = lm.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                            root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, out=lo)
+            e1.record()
+            lev.append((e0, e1))
+        torch.cuda.synchronize()
+        lm_ms = float(np.mean([a.elapsed_time(b) for a, b in lev[1:]]))
+        lerr = torch.linalg.norm((eng.fk(lo["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
+                                  - kp.reshape(-1, fs.tables.nsite, 3)), dim=-1)
+        line["config"]["lm_solver_same_batch"] = {
+            "frames_per_s": frames_step / (lm_ms * 1e-3), "kernel_ms": lm_ms,
+            "marker_rmse_mm": float(torch.sqrt((lerr ** 2).mean()).item() * 1e3),
+            "note": "stac_q_params.solver = STAC_SOLVER_LM; not the reference's algorithm, judged in marker space only"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.solver == "pg":
         line["cpu_baseline"] = cpu_baseline(fs, cfg, kp_host)
     if rank == 0:

@@ -286,7 +286,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
             for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) mm = std::max(mm, ab_jnum[s]);
             mfirst[l + 1] = mfirst[l] + mm;
         }
-        const int n_mlev = mfirst[nlev];
+        const int n_mlev = (mfirst[nlev] + 1) & ~1;  // even: the kernel runs two steps per loop trip (an empty level pads)
         std::vector<int32_t> prog((size_t)n_mlev * W * rw, 0);
         auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
         for (int l = 0; l < nlev; ++l)
@@ -356,16 +356,18 @@ constexpr int kCus = 256;
 // Wavefronts per workgroup: the waves of a block share one copy of the plan, so more chains fit the
 // 160 KiB of a CU.  Returns the wpb (1..8) that maximises resident chains per CU for this G.
 // Launch shape for a given G: wavefronts per workgroup (the waves of a block share one plan copy) and the
-// register-cap variant.  wpe = 2 keeps everything in registers (<= 256 VGPRs, 8 waves per CU); wpe = 4
-// (<= 128 VGPRs, some spills to scratch) admits 16 waves per CU and is used when LDS leaves room for more
-// than 8 waves.  LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not
+// register-cap variant.  wpe = 2 keeps everything in registers (<= 256 VGPRs, 8 waves per CU); wpe = 3
+// (<= 168 VGPRs, 16-lane groups only) holds ten waves as ONE workgroup (3,3,2,2 over the SIMDs; two 5-wave
+// workgroups could stack four waves on a SIMD); wpe = 4 (<= 128 VGPRs, more spills to scratch) admits 16 waves
+// per CU.  LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not
 // fit a CU).
 struct QShape { int wpb, wpe, waves_per_cu; };
 static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_needed = -1) {
     constexpr size_t kGranule = 1280;
     QShape best{0, 2, 0};
-    for (int wpe = 2; wpe <= 4; wpe += 2) {
-        for (int wpb = 1; wpb <= 8; ++wpb) {
+    for (int wpe = 2; wpe <= 4; ++wpe) {
+        if (wpe == 3 && G != 16) continue;  // the 168-VGPR variant (one 10-wave workgroup per CU) exists for 16-lane groups
+        for (int wpb = 1; wpb <= (wpe == 3 ? 10 : 8); ++wpb) {
             size_t lds = q_lds_bytes(h, G, nkinds, wpb);
             if (lds > kLdsPerCu) break;
             lds = (lds + kGranule - 1) / kGranule * kGranule;
@@ -379,8 +381,9 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_need
                 if (blocks * per_simd > wpe) blocks = wpe / per_simd;
             }
             const int waves = blocks * wpb;
-            // prefer more resident waves; on ties the variant without spills, then the smaller workgroup
-            if (waves > best.waves_per_cu) best = QShape{wpb, wpe, waves};
+            // prefer more resident waves, then the smaller workgroup; a variant with a tighter register cap (more
+            // spills) has to bring at least 20 % more waves than the best roomier one
+            if (wpe == best.wpe ? waves > best.waves_per_cu : waves * 5 >= best.waves_per_cu * 6) best = QShape{wpb, wpe, waves};
             // few chains: the first shape that holds every wave at once is enough -- small workgroups spread
             // over more CUs and the 2-waves-per-SIMD variant does not spill
             if (waves_needed >= 0 && (long)waves * kCus >= waves_needed) return QShape{wpb, wpe, waves};
@@ -547,11 +550,11 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             const QShape shp = pick_shape(hp, G, nkinds, waves_needed);
             if (shp.wpb && shp.waves_per_cu >= sh.waves_per_cu) { sh = shp; a.h.total_words = m->h.total_words; a.flags &= ~2; }
         }
+        if (const char *w = getenv("STAC_HIP_WPE")) sh.wpe = atoi(w) >= 4 ? 4 : (atoi(w) == 3 && G == 16) ? 3 : 2;
         if (const char *w = getenv("STAC_HIP_WPB")) {  // developer overrides
             const int ww = atoi(w);
-            if (ww >= 1 && ww <= 8 && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
+            if (ww >= 1 && ww <= (sh.wpe == 3 ? 10 : 8) && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
         }
-        if (const char *w = getenv("STAC_HIP_WPE")) sh.wpe = atoi(w) >= 4 ? 4 : 2;
         if (getenv("STAC_HIP_VERBOSE"))
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
                     nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), m->h.chain_stride, a.h.total_words);

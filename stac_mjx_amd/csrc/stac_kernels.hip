@@ -113,6 +113,71 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
 // (micro-level, lane position), so the record and the joint-local quaternion of step k+1 are fetched while
 // step k computes and the serial chain holds no dependent LDS round trip except a parent transform that
 // another lane produced (branch points of the tree).  Requires max_width <= gf.  Bit-identical to fk_levels.
+struct FkRegs {
+    int4 r0;           // flags, parent, j, jnext
+    float4 r1, r2, r3; // body_pos | xf, jnt_pos | qadr, body_quat
+    Q4 ql;             // joint-local quaternion of the step's joint
+};
+template <int RW>
+__device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const float *qlb, const int jq, const bool on) {
+    R.r0 = lds4i(rec);
+    R.r1 = lds4(rec + 4);
+    R.r2 = lds4(rec + 8);
+    if constexpr (RW == 16) R.r3 = lds4(rec + 12);
+    if (!on) R.r0.x = 0;
+    R.ql = ld4(qlb + 7 * jq);
+}
+// One step: fetch the next step's record into N (its joint index is this record's jnext), then run this one.
+template <int RW>
+__device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float *next_rec, const bool on, V3 &pos, Q4 &quat,
+                                        float *bx, float *ja, const float *qe, const float *jrec, const bool store_ja) {
+    fk_fetch<RW>(N, next_rec, ja + 3, R.r0.w, on);
+    const int fl = R.r0.x;
+    if (fl & FK_BODY) {
+        if (fl & FK_PARENT_LDS) {
+            const float *pp = bx + R.r0.y * 7;
+            pos = ld3(pp);
+            quat = ld4(pp + 3);
+        }
+        pos = add3(pos, rotate(V3{R.r1.x, R.r1.y, R.r1.z}, quat));
+        if constexpr (RW == 16) {
+            if (fl & FK_BQUAT) quat = qmul(quat, Q4{R.r3.x, R.r3.y, R.r3.z, R.r3.w});  // identity: exact, skipped
+        }
+    }
+    if (fl & FK_JOINT) {
+        const int j = R.r0.z, ty = (fl >> FK_JTYPE_SHIFT) & 3;
+        const V3 jp = {R.r2.x, R.r2.y, R.r2.z};
+        const bool jzero = fl & FK_JZERO;  // rotate(0, q) is a zero vector: anchor = pos, pos stays (exact)
+        const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+        V3 anchor = pos;
+        if (ty == JHINGE || ty == JBALL) {
+            if (!jzero) anchor = add3(rotate(jp, quat), pos);
+            quat = qmul(quat, R.ql);
+            if (!jzero) pos = sub3(anchor, rotate(jp, quat));
+        } else if (ty == JFREE) {
+            const int ad = __builtin_bit_cast(int, R.r2.w);
+            anchor = ld3(qe + ad);
+            pos = anchor;
+            quat = R.ql;  // normalised by the pre-pass
+        } else {  // slide
+            if (!jzero) anchor = add3(rotate(jp, quat), pos);
+            const float4 ja4 = lds4(jrec + 12 * j + 8);
+            const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+            const float d = R.ql.w;
+            pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+        }
+        if (store_ja) {
+            st3(ja + 7 * j, anchor);
+            st4(ja + 7 * j + 3, prequat);
+        }
+    }
+    if (fl & FK_LAST) {
+        const int xf = __builtin_bit_cast(int, R.r1.w);
+        st3(bx + xf * 7, pos);
+        st4(bx + xf * 7 + 3, quat);
+    }
+    wave_sync();
+}
 template <int RW>
 __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
                                            const bool active, const bool store_ja) {
@@ -121,78 +186,20 @@ __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, 
     const float *sp = P + H.off_fkstep + RW * (on ? lf : 0);
     const float *jrec = P + H.off_joint;
     float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
-    const float *qe = CBc + H.c_qe, *qlb = CBc + H.c_ja + 3;
-    V3 cpos = {0.f, 0.f, 0.f};
-    Q4 cquat = {1.f, 0.f, 0.f, 0.f};
-    int4 r0 = lds4i(sp);
-    float4 r1 = lds4(sp + 4), r2 = lds4(sp + 8), r3 = {1.f, 0.f, 0.f, 0.f};
-    if constexpr (RW == 16) r3 = lds4(sp + 12);
-    if (!on) r0.x = 0;
-    Q4 qn = ld4(qlb + 7 * r0.z);
+    const float *qe = CBc + H.c_qe;
+    V3 pos = {0.f, 0.f, 0.f};  // the lane's running transform: a body that follows its parent on the same lane
+    Q4 quat = {1.f, 0.f, 0.f, 0.f};  // starts from it without touching LDS
+    FkRegs A, B;
+    A.r3 = B.r3 = float4{1.f, 0.f, 0.f, 0.f};
+    fk_fetch<RW>(A, sp, ja + 3, 0, on);
+    A.ql = ld4(ja + 3 + 7 * A.r0.z);
     const int stride = RW * W;
-    for (int ml = 0; ml < H.n_mlev; ++ml) {
-        // fetch the next step (the last iteration re-reads its own record: harmless)
-        const float *np = (ml + 1 < H.n_mlev) ? sp + stride : sp;
-        const int4 n0 = lds4i(np);
-        const float4 n1 = lds4(np + 4), n2 = lds4(np + 8);
-        float4 n3 = {1.f, 0.f, 0.f, 0.f};
-        if constexpr (RW == 16) n3 = lds4(np + 12);
-        const Q4 qnn = ld4(qlb + 7 * r0.w);
-        const int fl = r0.x;
-        if (fl) {
-            V3 pos = cpos;
-            Q4 quat = cquat;
-            if (fl & FK_BODY) {
-                if (fl & FK_PARENT_LDS) {
-                    const float *pp = bx + r0.y * 7;
-                    pos = ld3(pp);
-                    quat = ld4(pp + 3);
-                }
-                pos = add3(pos, rotate(V3{r1.x, r1.y, r1.z}, quat));
-                if constexpr (RW == 16) {
-                    if (fl & FK_BQUAT) quat = qmul(quat, Q4{r3.x, r3.y, r3.z, r3.w});  // identity: exact, skipped
-                }
-            }
-            if (fl & FK_JOINT) {
-                const int j = r0.z, ty = (fl >> FK_JTYPE_SHIFT) & 3;
-                const V3 jp = {r2.x, r2.y, r2.z};
-                const bool jzero = fl & FK_JZERO;  // rotate(0, q) is a zero vector: anchor = pos, pos stays (exact)
-                const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
-                V3 anchor = pos;
-                if (ty == JHINGE || ty == JBALL) {
-                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
-                    quat = qmul(quat, qn);
-                    if (!jzero) pos = sub3(anchor, rotate(jp, quat));
-                } else if (ty == JFREE) {
-                    const int ad = __builtin_bit_cast(int, r2.w);
-                    anchor = ld3(qe + ad);
-                    pos = anchor;
-                    quat = qn;  // normalised by the pre-pass
-                } else {  // slide
-                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
-                    const float4 ja4 = lds4(jrec + 12 * j + 8);
-                    const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
-                    const float d = qn.w;
-                    pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
-                }
-                if (store_ja) {
-                    st3(ja + 7 * j, anchor);
-                    st4(ja + 7 * j + 3, prequat);
-                }
-            }
-            if (fl & FK_LAST) {
-                const int xf = __builtin_bit_cast(int, r1.w);
-                st3(bx + xf * 7, pos);
-                st4(bx + xf * 7 + 3, quat);
-            }
-            cpos = pos;
-            cquat = quat;
-        }
-        wave_sync();
-        sp = np;
-        r0 = n0; r1 = n1; r2 = n2; r3 = n3;
-        if (!on) r0.x = 0;
-        qn = qnn;
+    // two steps per trip so that the fetched record never has to be copied (n_mlev is even: padded by the host)
+    for (int ml = 0; ml < H.n_mlev; ml += 2) {
+        sp += stride;
+        fk_step<RW>(A, B, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
+        if (ml + 2 < H.n_mlev) sp += stride;
+        fk_step<RW>(B, A, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
     }
 }
 
@@ -217,7 +224,7 @@ __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, fl
 // sequential algorithm would; its gradient gives the stopping residual and group 4+c* already holds
 // f, grad f at the next y: one trip per PG iteration instead of three, identical arithmetic per evaluation.
 template <int G, int NQR, int WPE, bool SPEC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+__global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
     static_assert(!SPEC || G == 8, "speculative mode uses the 8 groups of 8 lanes of one wavefront");
     extern __shared__ float lds[];
@@ -916,6 +923,9 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
 #define STAC_TRY(GG, RR)                                                          \
     if (G == GG && nq <= GG * RR) {                                               \
         *capacity_out = GG * RR;                                                  \
+        if constexpr (GG == 16) {                                                 \
+            if (wpe == 3) return launch_q<GG, RR, 3, false>(a, wpb, lds_bytes, s); \
+        }                                                                         \
         return wpe >= 4 ? launch_q<GG, RR, 4, false>(a, wpb, lds_bytes, s)        \
                         : launch_q<GG, RR, 2, false>(a, wpb, lds_bytes, s);       \
     }
