@@ -1,12 +1,25 @@
 #!/bin/bash
-# usage: gpurun_pmc.sh <tag> <bench args...>   (run on the GPU box from the repo root)
+# usage (on the GPU box, from the repo root): bash profiles/tools/collect_pmc.sh <tag> [bench.py args...]
+# Writes gpurun_out/prof_<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py <args>`),
+# one JSON per PMC pass (counter passes are separate runs: the TCC counters do not fit one pass), bench.json.
 tag=$1; shift
 R=$PWD
-mkdir -p $R/gpurun_out/pmc_$tag
+OUT=$R/gpurun_out/prof_$tag
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
-  n=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_$tag_$n --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /tmp/pmc_$tag_$n.log 2>&1
-  python3 $R/profiles/tools/pmc_summary.py /tmp/pmc_$tag_$n q_phase > $R/gpurun_out/pmc_$tag/$n.json
+rm -rf /tmp/rp_${tag}_stats
+rocprofv3 --kernel-trace --stats -d /tmp/rp_${tag}_stats --output-format csv -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
+f=$(find /tmp/rp_${tag}_stats -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $OUT/kernel_stats.csv
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rm -rf /tmp/rp_${tag}_$i
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/rp_${tag}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /tmp/rp_${tag}_$i.log 2>&1
+  python3 $R/profiles/tools/pmc_summary.py /tmp/rp_${tag}_$i q_phase > $OUT/pmc_pass$i.json
 done
-cat $R/gpurun_out/pmc_$tag/*.json
+tail -1 $OUT/bench.json | cut -c1-200
+head -5 $OUT/kernel_stats.csv
+cat $OUT/pmc_pass3.json $OUT/pmc_pass4.json | grep -E "SIZE|Scratch"
