@@ -700,8 +700,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     if (rc != STAC_OK) return rc;
     a.hdr = nullptr;
     a.plan = m->d_blob;
-    a.h = m->h;
-    a.h.total_words = m->h.core_words;  // the LM kernel walks the levels itself: no FK program in LDS
+    a.h = m->h;  // total_words (what the launch stages in LDS) is settled with the launch shape below
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const LmArgs &L = m->lm_args;
 #ifdef STAC_PROFILE
@@ -718,19 +717,36 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
         const int cpw = 64 / G;
         const int mbw = (2 * nkinds * G + 3) & ~3, khw = ((nkinds * kLmKindWords + 3) & ~3) + ((L.hot_words + 3) & ~3) +
                                                    ((((L.maxpd * (L.maxpd + 1)) >> 1) + 3) & ~3);
-        auto lds_for = [&](int wpb) { return (size_t)(((m->h.core_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
-        int wpb = 0, best_waves = 0;
+        int plan_words = m->h.core_words;
+        auto lds_for = [&](int wpb) { return (size_t)(((plan_words + 3) & ~3) + mbw + khw + wpb * cpw * L.chain_stride) * sizeof(float); };
         const int wps = lm_waves_per_simd(G, m->h.nq);
-        for (int w = 1; w <= 8; ++w) {
-            size_t lds = lds_for(w);
-            if (lds > kLdsPerCu) break;
-            lds = (lds + 1279) / 1280 * 1280;
-            int blocks = (int)(kLdsPerCu / lds);
-            if (w <= 4) { if (blocks * w > 4 * wps) blocks = 4 * wps / w; }
-            else { const int per_simd = (w + 3) / 4; if (blocks * per_simd > wps) blocks = wps / per_simd; }
-            if (blocks * w > best_waves) { best_waves = blocks * w; wpb = w; }
-        }
+        auto best_shape = [&](int &wpb_out) {
+            int best = 0;
+            wpb_out = 0;
+            for (int w = 1; w <= 8; ++w) {
+                size_t lds = lds_for(w);
+                if (lds > kLdsPerCu) break;
+                lds = (lds + 1279) / 1280 * 1280;
+                int blocks = (int)(kLdsPerCu / lds);
+                if (w <= 4) { if (blocks * w > 4 * wps) blocks = 4 * wps / w; }
+                else { const int per_simd = (w + 3) / 4; if (blocks * per_simd > wps) blocks = wps / per_simd; }
+                if (blocks * w > best) { best = blocks * w; wpb_out = w; }
+            }
+            return best;
+        };
+        int wpb = 0;
+        int best_waves = best_shape(wpb);
         if (!wpb) continue;
+        // the FK program (stac_plan.hpp) is staged only if every level fits the lane group and it costs no occupancy
+        a.flags |= 2;
+        a.h.total_words = m->h.core_words;
+        if (m->h.max_width <= G && !(getenv("STAC_HIP_FLAGS") && (atoi(getenv("STAC_HIP_FLAGS")) & 2))) {
+            plan_words = m->h.total_words;
+            int wpb2 = 0;
+            const int waves2 = best_shape(wpb2);
+            if (wpb2 && waves2 >= best_waves) { wpb = wpb2; best_waves = waves2; a.flags &= ~2; a.h.total_words = m->h.total_words; }
+            else plan_words = m->h.core_words;
+        }
         a.mb_words = mbw;
         if (getenv("STAC_HIP_VERBOSE"))
             fprintf(stderr, "[stac] q_phase LM: chains=%d G=%d wpb=%d waves/CU=%d lds=%zu B/block chain_stride=%d n_max=%d maxpd=%d\n",

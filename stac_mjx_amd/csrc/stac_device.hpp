@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "stac_plan.hpp"
+
 namespace stac {
 
 // ------------------------------------------------------------------------------------------------
@@ -142,5 +144,221 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast<const int4 *>(p); }
+
+// ------------------------------------------------------------------------------------------------
+// forward kinematics of one chain out of LDS (shared by the PG and the LM kernel)
+// ------------------------------------------------------------------------------------------------
+// Joint-local transforms: everything of the kinematics that depends on q alone, one lane per joint (hinge: the
+// half-angle sincos and the local quaternion; free / ball: the normalised quaternion, written back like MJX does;
+// slide: the displacement).  This keeps the sincos off the serial chain of the FK that follows.  The result sits in
+// the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
+__device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf) {
+    const float *jrec = P + H.off_joint;
+    float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *qlb = CBc + H.c_ja + 3;
+    for (int j = lf; j < H.naj; j += gf) {
+        const float *jr = jrec + 12 * j;
+        const int4 ji = lds4i(jr);  // type, qadr, slo, shi
+        const int ty = ji.x, ad = ji.y;
+        if (ty == JHINGE) {
+            const float4 jp4 = lds4(jr + 4);  // pos, q0
+            const float4 ja4 = lds4(jr + 8);  // axis, slot
+            const float angle = qe[ad] - jp4.w;
+            float sn, cs;
+            sincos_(angle * 0.5f, &sn, &cs);
+            st4(qlb + 7 * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
+        } else if (ty == JSLIDE) {
+            const float4 jp4 = lds4(jr + 4);
+            qlb[7 * j] = qe[ad] - jp4.w;
+        } else {
+            const int qa = ty == JFREE ? ad + 3 : ad;
+            float n;
+            const Q4 qn = normalize4(ld4(qe + qa), &n);
+            st4(qe + qa, qn);  // written back, like MJX
+            st4(qlb + 7 * j, qn);
+            jn[j] = n;
+        }
+    }
+}
+
+// Forward kinematics of one chain, level by level (mjx smooth.kinematics), by gf lanes (lf = this
+// lane's index among them): reads the evaluation point qe (quaternions already normalised) and the joint-local
+// quaternions ql, writes the body transforms bx and, if store_ja, every joint's anchor and pre-joint quaternion.
+// A lane keeps the transform of the body it has just finished: the host lays the levels out so that a body sits
+// at its parent's position in the level wherever it can (flag bit 1), and then the parent transform never makes
+// the LDS round trip.  All lanes of the wavefront must call it together (wave-level synchronisation per level).
+__device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                          const bool active, const bool store_ja) {
+    const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
+    const float *brec = P + H.off_body, *jrec = P + H.off_joint;
+    float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
+    const float *qe = CBc + H.c_qe, *qlb = CBc + H.c_ja + 3;
+    const bool carry_ok = H.max_width <= gf;  // every level is a single pass
+    V3 cpos = {0.f, 0.f, 0.f};
+    Q4 cquat = {1.f, 0.f, 0.f, 0.f};
+    for (int lev = 0; lev < H.nlev; ++lev) {
+        const int s_end = active ? lev_adr[lev + 1] : 0;
+        for (int s = lev_adr[lev] + lf; s < s_end; s += gf) {
+            const float *br = brec + 12 * s;
+            const int4 bi = lds4i(br);       // parent, jadr, jnum, flags
+            const float4 bp = lds4(br + 4);  // pos, zero-jnt_pos bits
+            V3 ppos = cpos;
+            Q4 pquat = cquat;
+            if (!(carry_ok && (bi.w & 2))) {
+                const float *pp = bx + bi.x * 7;
+                ppos = ld3(pp);
+                pquat = ld4(pp + 3);
+            }
+            V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
+            Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
+            if (!(bi.w & 1)) {
+                const float4 bq = lds4(br + 8);
+                quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
+            }
+            const int jz = __builtin_bit_cast(int, bp.w);
+            for (int jj = 0; jj < bi.z; ++jj) {
+                const int j = bi.y + jj;
+                const float *jr = jrec + 12 * j;
+                const int4 ji = lds4i(jr);        // type, qadr, slo, shi
+                const float4 jp4 = lds4(jr + 4);  // pos, q0
+                const int ty = ji.x, ad = ji.y;
+                const V3 jp = {jp4.x, jp4.y, jp4.z};
+                // jnt_pos == 0: rotate(0, q) is a zero vector, so anchor = pos and pos stays (exact)
+                const bool jzero = jj < 31 && ((jz >> jj) & 1);
+                const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+                V3 anchor = pos;
+                if (ty == JHINGE || ty == JBALL) {
+                    const Q4 qloc = ld4(qlb + 7 * j);
+                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                    quat = qmul(quat, qloc);
+                    if (!jzero) pos = sub3(anchor, rotate(jp, quat));
+                } else if (ty == JFREE) {
+                    anchor = ld3(qe + ad);
+                    pos = anchor;
+                    quat = ld4(qe + ad + 3);  // normalised by the pre-pass
+                } else {  // slide
+                    if (!jzero) anchor = add3(rotate(jp, quat), pos);
+                    const float4 ja4 = lds4(jr + 8);
+                    const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+                    const float d = qlb[7 * j];
+                    pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+                }
+                if (store_ja) {
+                    st3(ja + 7 * j, anchor);
+                    st4(ja + 7 * j + 3, prequat);
+                }
+            }
+            st3(bx + (s + 1) * 7, pos);
+            st4(bx + (s + 1) * 7 + 3, quat);
+            cpos = pos;
+            cquat = quat;
+        }
+        wave_sync();
+    }
+}
+
+// The same kinematics driven by the FK "program" (FkStep records, stac_plan.hpp): one fixed-size record per
+// (micro-level, lane position), so the record and the joint-local quaternion of step k+1 are fetched while
+// step k computes and the serial chain holds no dependent LDS round trip except a parent transform that
+// another lane produced (branch points of the tree).  Requires max_width <= gf.  Bit-identical to fk_levels.
+struct FkRegs {
+    int4 r0;           // flags, parent, j, jnext
+    float4 r1, r2, r3; // body_pos | xf, jnt_pos | qadr, body_quat
+    Q4 ql;             // joint-local quaternion of the step's joint
+};
+template <int RW>
+__device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const float *qlb, const int jq, const bool on) {
+    R.r0 = lds4i(rec);
+    R.r1 = lds4(rec + 4);
+    R.r2 = lds4(rec + 8);
+    if constexpr (RW == 16) R.r3 = lds4(rec + 12);
+    if (!on) R.r0.x = 0;
+    R.ql = ld4(qlb + 7 * jq);
+}
+// One step: fetch the next step's record into N (its joint index is this record's jnext), then run this one.
+template <int RW>
+__device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float *next_rec, const bool on, V3 &pos, Q4 &quat,
+                                        float *bx, float *ja, const float *qe, const float *jrec, const bool store_ja) {
+    fk_fetch<RW>(N, next_rec, ja + 3, R.r0.w, on);
+    const int fl = R.r0.x;
+    if (fl & FK_BODY) {
+        if (fl & FK_PARENT_LDS) {
+            const float *pp = bx + R.r0.y * 7;
+            pos = ld3(pp);
+            quat = ld4(pp + 3);
+        }
+        pos = add3(pos, rotate(V3{R.r1.x, R.r1.y, R.r1.z}, quat));
+        if constexpr (RW == 16) {
+            if (fl & FK_BQUAT) quat = qmul(quat, Q4{R.r3.x, R.r3.y, R.r3.z, R.r3.w});  // identity: exact, skipped
+        }
+    }
+    if (fl & FK_JOINT) {
+        const int j = R.r0.z, ty = (fl >> FK_JTYPE_SHIFT) & 3;
+        const V3 jp = {R.r2.x, R.r2.y, R.r2.z};
+        const bool jzero = fl & FK_JZERO;  // rotate(0, q) is a zero vector: anchor = pos, pos stays (exact)
+        const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+        V3 anchor = pos;
+        if (ty == JHINGE || ty == JBALL) {
+            if (!jzero) anchor = add3(rotate(jp, quat), pos);
+            quat = qmul(quat, R.ql);
+            if (!jzero) pos = sub3(anchor, rotate(jp, quat));
+        } else if (ty == JFREE) {
+            const int ad = __builtin_bit_cast(int, R.r2.w);
+            anchor = ld3(qe + ad);
+            pos = anchor;
+            quat = R.ql;  // normalised by the pre-pass
+        } else {  // slide
+            if (!jzero) anchor = add3(rotate(jp, quat), pos);
+            const float4 ja4 = lds4(jrec + 12 * j + 8);
+            const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+            const float d = R.ql.w;
+            pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+        }
+        if (store_ja) {
+            st3(ja + 7 * j, anchor);
+            st4(ja + 7 * j + 3, prequat);
+        }
+    }
+    if (fl & FK_LAST) {
+        const int xf = __builtin_bit_cast(int, R.r1.w);
+        st3(bx + xf * 7, pos);
+        st4(bx + xf * 7 + 3, quat);
+    }
+    wave_sync();
+}
+template <int RW>
+__device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                           const bool active, const bool store_ja) {
+    const int W = H.max_width;
+    const bool on = active && lf < W;
+    const float *sp = P + H.off_fkstep + RW * (on ? lf : 0);
+    const float *jrec = P + H.off_joint;
+    float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
+    const float *qe = CBc + H.c_qe;
+    V3 pos = {0.f, 0.f, 0.f};  // the lane's running transform: a body that follows its parent on the same lane
+    Q4 quat = {1.f, 0.f, 0.f, 0.f};  // starts from it without touching LDS
+    FkRegs A, B;
+    A.r3 = B.r3 = float4{1.f, 0.f, 0.f, 0.f};
+    fk_fetch<RW>(A, sp, ja + 3, 0, on);
+    A.ql = ld4(ja + 3 + 7 * A.r0.z);
+    const int stride = RW * W;
+    // two steps per trip so that the fetched record never has to be copied (n_mlev is even: padded by the host)
+    for (int ml = 0; ml < H.n_mlev; ml += 2) {
+        sp += stride;
+        fk_step<RW>(A, B, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
+        if (ml + 2 < H.n_mlev) sp += stride;
+        fk_step<RW>(B, A, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
+    }
+}
+
+// FK of one chain by gf lanes: the program when every level fits the lanes, else the level loop.
+__device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                         const bool active, const bool store_ja, const bool use_levels) {
+    if (H.max_width <= gf && !use_levels) {
+        if (H.fk_rec_words == 16) fk_program<16>(H, P, CBc, lf, gf, active, store_ja);
+        else fk_program<12>(H, P, CBc, lf, gf, active, store_ja);
+    } else {
+        fk_levels(H, P, CBc, lf, gf, active, store_ja);
+    }
+}
 
 }  // namespace stac

@@ -151,60 +151,10 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
         }
         wave_sync();
 
-        // ---- forward kinematics (same operation sequence as the PG kernel) -----------------------------------------
-        for (int lev = 0; lev < H.nlev; ++lev) {
-            const int s_end = lev_adr[lev + 1];
-            for (int s = lev_adr[lev] + lg; s < s_end; s += G) {
-                const float *br = brec + 12 * s;
-                const int4 bi = lds4i(br);
-                const float4 bp = lds4(br + 4);
-                const float *pp = bx + bi.x * 7;
-                const Q4 pquat = ld4(pp + 3);
-                V3 pos = add3(ld3(pp), rotate(V3{bp.x, bp.y, bp.z}, pquat));
-                Q4 quat = pquat;
-                if (!(bi.w & 1)) {
-                    const float4 bq = lds4(br + 8);
-                    quat = qmul(pquat, Q4{bq.x, bq.y, bq.z, bq.w});
-                }
-                const int j1 = bi.y + bi.z;
-                for (int j = bi.y; j < j1; ++j) {
-                    const float *jr = jrec + 12 * j;
-                    const int4 ji = lds4i(jr);
-                    const float4 jp4 = lds4(jr + 4);
-                    const float4 ja4 = lds4(jr + 8);
-                    const int ty = ji.x, ad = ji.y;
-                    const V3 jp = {jp4.x, jp4.y, jp4.z}, jax = {ja4.x, ja4.y, ja4.z};
-                    V3 anchor;
-                    const Q4 prequat = quat;
-                    if (ty == JHINGE) {
-                        anchor = add3(rotate(jp, quat), pos);
-                        float sn, cs;
-                        sincos_((qe[ad] - jp4.w) * 0.5f, &sn, &cs);
-                        quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
-                        pos = sub3(anchor, rotate(jp, quat));
-                    } else if (ty == JFREE) {
-                        anchor = ld3(qe + ad);
-                        pos = anchor;
-                        float n;
-                        quat = normalize4(ld4(qe + ad + 3), &n);
-                        st4(qe + ad + 3, quat);
-                        jn[j] = n;
-                    } else if (ty == JSLIDE) {
-                        anchor = add3(rotate(jp, quat), pos);
-                        const V3 axis = rotate(jax, quat);
-                        const float d = qe[ad] - jp4.w;
-                        pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
-                    } else {  // ball joints are rejected on the host for this solver
-                        anchor = pos;
-                    }
-                    st3(ja + 7 * j, anchor);
-                    st4(ja + 7 * j + 3, prequat);
-                }
-                st3(bx + (s + 1) * 7, pos);
-                st4(bx + (s + 1) * 7 + 3, quat);
-            }
-            wave_sync();
-        }
+        // ---- forward kinematics: the PG kernel's joint-local pre-pass + FK program (stac_device.hpp) -------------------
+        joint_local_prepass(H, P, CB, lg, G);
+        wave_sync();
+        fk_chain(H, P, CB, lg, G, true, true, (a.flags & 2) != 0);
 
         PROF_TICK(1);  // stage + FK
         // ---- sites: world position (kept for the Jacobian), residual, loss term, wrench -------------------------------
