@@ -686,7 +686,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     o = (o + 3) & ~3;
     L.c_A = o; o += L.npk;
     L.c_b = o; o += L.n_max;
-    L.c_d = o; o += L.n_max;
+    L.c_d = o; o += L.n_max + 2 * L.maxpd;  // step vector + two scratch rows of the L^T D L pivot loop
     L.c_fz = o; o += L.n_max;
     if ((o & 1) == 0) o += 1;
     L.chain_stride = o;

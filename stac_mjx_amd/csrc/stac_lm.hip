@@ -358,27 +358,42 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             PROF_TICK(7);  // damped matrix
             if (solving) {
                 const int *anc = KT + kh.off_anc;
+                // Per pivot k (leaves first): (A) for p < pd(k): l_p = H[k][p] / H[k][k] into a scratch row (the pivot
+                // row itself is still read by (B)), y = L^-T b on the fly (b[anc_p] -= l_p b[k]), and the previous
+                // pivot's scratch row goes to its final place L[k+1][.]; (B) pairs (p_i >= p_j):
+                // H[anc_i][p_j] -= l_i H[k][p_j].  Two wave-level syncs and pd(k) divisions per pivot.
+                float *lrow = dv + L.n_max;  // two scratch rows of maxpd floats, used alternately
+                int kprev = -1, pdprev = 0;
                 for (int k = n - 1; k >= 0; --k) {
                     const int pdk = KT[kh.off_dof + 4 * k + 3];
                     const float *Hk = Hc + k * mp;
                     const float dkk = Hk[pdk];
                     if (!(dkk > 0.0f)) bad = true;
-                    // a_p = H[k][p] / H[k][k] for the ancestors p < pd(k); pairs (p_i >= p_j): H[anc_i][p_j] -= a_i H[k][p_j]
+                    float *lcur = lrow + (k & 1) * mp;
+                    const float *lold = lrow + ((k + 1) & 1) * mp;
+                    for (int p = lg; p < pdprev; p += G) Hc[kprev * mp + p] = lold[p];
+                    const float bk = dv[k];
+                    for (int p = lg; p < pdk; p += G) {
+                        const float l = Hk[p] / dkk;
+                        lcur[p] = l;
+                        const int ai = anc[k * mp + p];
+                        dv[ai] = FMA(-l, bk, dv[ai]);
+                    }
+                    wave_sync();
                     const int T = (pdk * (pdk + 1)) >> 1;
                     for (int q = lg; q < T; q += G) {
                         const int pij = TRI[q], pi = pij >> 8, pj = pij & 0xFF;
                         const int ai = anc[k * mp + pi];
-                        const float av = Hk[pi] / dkk;
-                        Hc[ai * mp + pj] = FMA(-av, Hk[pj], Hc[ai * mp + pj]);
+                        Hc[ai * mp + pj] = FMA(-lcur[pi], Hk[pj], Hc[ai * mp + pj]);
                     }
                     wave_sync();
-                    for (int p = lg; p < pdk; p += G) Hc[k * mp + p] = Hk[p] / dkk;  // L[k][p]
-                    // y = L^-T b: b[anc] -= L[k][anc] b[k]
-                    wave_sync();
-                    const float bk = dv[k];
-                    for (int p = lg; p < pdk; p += G) { const int ai = anc[k * mp + p]; dv[ai] = FMA(-Hc[k * mp + p], bk, dv[ai]); }
-                    wave_sync();
+                    kprev = k; pdprev = pdk;
                 }
+                if (kprev >= 0) {
+                    const float *lold = lrow + (kprev & 1) * mp;
+                    for (int p = lg; p < pdprev; p += G) Hc[kprev * mp + p] = lold[p];
+                }
+                wave_sync();
                 PROF_TICK(8);  // L^T D L + backward pass
                 // z = D^-1 y, then d = L^-1 z.  A dof only depends on the dofs of its own root path: every lane
                 // keeps the running value of its dofs in registers; depth by depth the finished dofs are published

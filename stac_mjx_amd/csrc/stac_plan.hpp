@@ -165,7 +165,7 @@ struct LmArgs {
     int32_t c_jp;          // [K * maxpd * 3] weighted Jacobian blocks; aliased by the factor H[npk]
     int32_t c_A;           // [npk] J^T W J (+ gauge term), row b holds its root-path columns: A[b * maxpd + pd(a)]
     int32_t c_b;           // [n_max] J^T W (kp - x)
-    int32_t c_d;           // [n_max] step
+    int32_t c_d;           // [n_max + 2 maxpd] step, then two scratch rows of the pivot loop
     int32_t c_fz;          // [n_max] 1.0 where the coordinate is frozen at a bound
     int32_t chain_stride;  // PG stride + extras (odd)
 };
