@@ -114,6 +114,29 @@ def test_q_phase_ik_clips_bit_exact(rodent_setup, rodent_mocap, lanes):
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
 
 
+@pytest.mark.parametrize("flags", ["0", "2"])
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_q_phase_fk_program_and_level_loop_agree(rodent_setup, fly_setup, rodent_mocap, monkeypatch, flags, lanes):
+    """The kernel has two FK implementations (prefetched step records vs walking the level tables; STAC_HIP_FLAGS
+    bit 1 forces the second, and the fly's 6-wide levels on 4-lane groups force it too): both equal the oracle."""
+    monkeypatch.setenv("STAC_HIP_FLAGS", flags)
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=lanes), _oracle(fs)
+    kp = rodent_mocap[600:610].reshape(5, 2, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims))
+    fly = fly_setup  # tethered: no root optimisation
+    engf, orcf = _engine(fly, lanes_per_chain=lanes, maxiter=30), _oracle(fly, maxiter=30)
+    rng = np.random.default_rng(11)
+    qt = fly.tables.qpos0[None] + np.clip(rng.normal(0, 0.1, (4, fly.tables.nq)), -0.2, 0.2).astype(np.float32)
+    qt[:, 3:7] = fly.tables.qpos0[3:7]
+    kpf = np.stack([orcf.fk(q)["site_xpos"].reshape(-1) for q in qt]).reshape(2, 2, 3 * fly.tables.nsite)
+    kpf = kpf + rng.normal(0, 1e-3, kpf.shape).astype(np.float32)
+    resf = engf.q_phase(kpf, part_masks=fly.part_masks)
+    _compare_phase(resf, orcf.ik_clips(kpf, fly.lb, fly.ub, fly.part_masks, fly.trunk_kps, 0, 7, do_root_opt=False))
+
+
 def test_q_phase_carried_chain_no_root_opt(rodent_setup, rodent_mocap):
     """fit_offsets semantics: one chain continued across calls with q_init (stac.py:298-311)."""
     fs = rodent_setup
