@@ -33,13 +33,16 @@ def main():
     ap.add_argument("--fit-frames", type=int, default=1000)
     ap.add_argument("--ik-frames", type=int, default=100000)
     ap.add_argument("--n-iters", type=int, default=6)
+    ap.add_argument("--fit-frames-per-clip", type=int, default=0,
+                    help="0 = the reference's single warm-started chain; F > 0 = independent clips of F fit frames (engine extension)")
     args = ap.parse_args()
     g = ROOT / "tests" / "golden"
     mcfg = json.load(open(g / "rodent_model_cfg.json"))
     mcfg["N_ITERS"] = args.n_iters
     stac_cfg = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="-", continuous=False,
                     n_fit_frames=args.fit_frames, skip_fit_offsets=False, skip_ik_only=False, infer_qvels=False,
-                    n_frames_per_clip=250, mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+                    n_frames_per_clip=250, mujoco=dict(solver="newton", iterations=1, ls_iterations=4),
+                    fit_frames_per_clip=args.fit_frames_per_clip)
     cfg = validate_config({"model": mcfg, "stac": stac_cfg})
     kp_names = list(mcfg["KEYPOINT_MODEL_PAIRS"].keys())
     fs = finish_fit_setup(ModelTables.load(g / "rodent_tables.npz"), mcfg, kp_names)
@@ -55,7 +58,8 @@ def main():
     torch.cuda.synchronize()
     t_fit = time.perf_counter() - t0
     print(f"fit_offsets: {args.fit_frames} frames x ({args.n_iters} + 1) pose passes in {t_fit:.1f} s "
-          f"({args.fit_frames * (args.n_iters + 1) / t_fit:.0f} frame-solves/s on ONE warm-started chain); "
+          f"({args.fit_frames * (args.n_iters + 1) / t_fit:.0f} frame-solves/s, "
+          f"{'ONE warm-started chain' if not args.fit_frames_per_clip else str(args.fit_frames // args.fit_frames_per_clip) + ' independent clips'}); "
           f"mean marker error {marker_err(fit, kp):.2f} mm; max |offset change| "
           f"{np.abs(fit.offsets - fs.tables.site_pos).max() * 1e3:.1f} mm")
 

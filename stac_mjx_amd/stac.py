@@ -70,14 +70,31 @@ class Stac:
 
     # -- fit_offsets (stac.py:253-354) ------------------------------------------------------------------
     def fit_offsets(self, kp_data, time_indices=None) -> StacData:
-        """Alternate pose and offset optimisation on ONE warm-started chain over all frames.
+        """Alternate pose and offset optimisation.
+
+        Default (the reference, ``stac.py:298-341``): ONE warm-started chain over all frames, carried across the
+        calibration iterations -- a serial computation, run on this rank's GPU (replicas only).
+
+        ``stac.fit_frames_per_clip: F`` (engine extension, not the reference's sequencing): the fit frames are cut
+        into clips of F frames; every clip is its own chain (root-optimised in the first pass, carried across the
+        iterations), the clips are sharded over the ranks and the offset phase all-reduces its 3K + 2 partial sums.
 
         ``time_indices`` (optional) overrides the PRNGKey(0) frame sample of the offset phase.
         """
         cfgm = self.cfg.model
         eng = self.engine
-        kp = torch.as_tensor(np.asarray(kp_data, dtype=np.float32)).to(eng.device)
-        n = kp.shape[0]
+        fpc = int(self.cfg.stac.get("fit_frames_per_clip", 0) or 0)
+        kp_np = np.asarray(kp_data, dtype=np.float32)
+        if fpc > 0:
+            kp_np = utils.batch_kp_data(kp_np, fpc, continuous=False)  # [C, F, 3K]; a ragged tail is dropped
+            if kp_np.shape[0] == 0:
+                raise ValueError(f"fit_frames_per_clip = {fpc} exceeds the {len(kp_data)} fit frames")
+        else:
+            kp_np = kp_np[None]
+        n_clips, n_per = kp_np.shape[0], kp_np.shape[1]
+        n = n_clips * n_per
+        lo, hi = dist.shard_range(n_clips) if fpc > 0 else (0, 1)
+        kp = torch.as_tensor(kp_np[lo:hi]).to(eng.device)
         self._offsets = eng.get_site_pos().clone()
         do_root = self.setup.do_root_opt
         if self._root_kp_idx == -1:
@@ -87,7 +104,9 @@ class Stac:
         n_sample = int(cfgm.N_SAMPLE_FRAMES)
         if time_indices is None:
             time_indices = prng.sample_time_indices(n, n_sample, seed=0)
-        idx = torch.as_tensor(np.asarray(time_indices), dtype=torch.long, device=eng.device)
+        tix = np.asarray(time_indices, dtype=np.int64)
+        mine = tix[(tix >= lo * n_per) & (tix < hi * n_per)] - lo * n_per  # sampled frames that live on this rank
+        idx = torch.as_tensor(mine, dtype=torch.long, device=eng.device)
         is_reg = torch.as_tensor(self._is_regularized).to(eng.device)
         carry = None
         res = None
@@ -96,20 +115,24 @@ class Stac:
             self._log("Final pose optimization" if final else f"Calibration iteration: {n_iter + 1}/{cfgm.N_ITERS}")
             # root optimisation happens once, before the first pose pass (stac.py:277-296); the warm start is
             # carried across iterations and into the final pass (stac.py:300-301,331-332)
-            res = self._q_phase(kp[None], do_root_opt=(do_root and n_iter == 0), q_init=carry, want_outputs=final)
+            res = self._q_phase(kp, do_root_opt=(do_root and n_iter == 0), q_init=carry, want_outputs=final)
             carry = res["carry_qpos"]
             _, mean, std = self._get_error_stats(res["frame_error"].cpu().numpy())
             self._log(f"Mean: {mean}\nStandard deviation: {std}")
             if final:
                 break
             # offset phase (compute_stac.py:107-167): regularised toward the PREVIOUS iterate (stac.py:317-328)
-            partial = eng.m_partial(kp[idx], res["qpos"][0][idx])
-            partial = dist.all_reduce_partial(partial) if False else partial  # single chain: replicas only
+            nq = self.setup.tables.nq
+            partial = eng.m_partial(kp.reshape(-1, kp.shape[-1])[idx], res["qpos"].reshape(-1, nq)[idx])
+            if fpc > 0:
+                partial = dist.all_reduce_partial(partial)  # the one data-path collective: 3K + 2 floats
             new_off, err = eng.m_finish(partial, self._offsets, is_reg, float(cfgm.M_REG_COEF))
             self._log(f"Final residual error of {float(err)}")
             eng.set_site_pos(new_off)
             self._offsets = new_off
-        return self._package_data(res, kp.cpu().numpy(), batched=False)
+        if fpc > 0 and dist.is_dist():
+            res = {k: (dist.all_gather_clips(v, n_clips) if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
+        return self._package_data(res, kp_np.reshape(n, -1), batched=fpc > 0)
 
     # -- ik_only (stac.py:356-454) --------------------------------------------------------------------------
     def ik_only(self, kp_data, offsets) -> StacData:

@@ -147,3 +147,90 @@ def test_lm_solver_through_the_config_surface(rodent_setup, rodent_cfg, rodent_m
     assert out["lm"][1].qpos.shape == (40, 74) and np.isfinite(out["lm"][1].qpos).all()
     assert out["lm"][2] <= out["pg"][2] + 2e-4, (out["lm"][2], out["pg"][2])
     assert np.abs(out["lm"][0].offsets - out["pg"][0].offsets).max() < 2e-2  # same calibration up to solver differences
+
+
+def _oracle_fit_offsets_clips(fs, cfgm, kp, n_iters, fpc):
+    """Restatement of the clip-parallel calibration (stac.fit_frames_per_clip): every clip is a root-optimised chain
+    carried across the iterations; the offset phase sums its statistics over the sampled frames of all clips."""
+    from oracle import Oracle
+    from stac_mjx_amd.prng import sample_time_indices
+
+    orc = Oracle(fs.tables, tol=float(cfgm["FTOL"]), maxiter=int(cfgm["N_ITER_Q"]))
+    C = kp.shape[0] // fpc
+    clips = kp[: C * fpc].reshape(C, fpc, -1)
+    offsets = fs.tables.site_pos.copy()
+    idx = sample_time_indices(C * fpc, int(cfgm["N_SAMPLE_FRAMES"]))
+    carry = None
+    for it in range(n_iters + 1):
+        out = orc.ik_clips(clips, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims,
+                           do_root_opt=(it == 0), q_init=carry)
+        carry = out["qpos"][:, -1]
+        if it == n_iters:
+            return offsets, out
+        offsets, _ = orc.m_opt(clips.reshape(C * fpc, -1)[idx], out["qpos"].reshape(C * fpc, -1)[idx], offsets,
+                               fs.is_regularized, float(cfgm["M_REG_COEF"]))
+        orc.set_site_pos(offsets)
+
+
+def test_fit_offsets_clip_parallel_extension(rodent_setup, rodent_cfg, rodent_mocap):
+    """stac.fit_frames_per_clip (engine extension): independent clips instead of one serial chain -- same kernels,
+    so it must still equal the oracle driven the same way, bit for bit."""
+    from stac_mjx_amd.stac import Stac
+
+    cfg = _cfg(rodent_cfg, fit_frames_per_clip=3)
+    cfg.model.N_ITERS = 2
+    kp = rodent_mocap[100:113]  # 13 frames -> 4 clips of 3, the ragged frame is dropped
+    stac = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False)
+    data = stac.fit_offsets(kp)
+    ref_off, ref = _oracle_fit_offsets_clips(rodent_setup, rodent_cfg, kp, 2, 3)
+    assert data.qpos.shape == (12, 74) and data.kp_data.shape == (12, 69)
+    np.testing.assert_array_equal(data.offsets, ref_off)
+    np.testing.assert_array_equal(data.qpos, ref["qpos"].reshape(12, 74))
+    np.testing.assert_array_equal(data.marker_sites, ref["marker_sites"].reshape(12, 23, 3))
+
+
+def _two_rank_fit(rank, port, tmp, kp, fpc):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        import json
+
+        from conftest import GOLDEN as G
+        from stac_mjx_amd.fit_model import finish_fit_setup
+        from stac_mjx_amd.mjcf import ModelTables
+        from stac_mjx_amd.stac import Stac
+
+        mcfg = json.load(open(G / "rodent_model_cfg.json"))
+        fs = finish_fit_setup(ModelTables.load(G / "rodent_tables.npz"), mcfg, list(mcfg["KEYPOINT_MODEL_PAIRS"].keys()))
+        cfg = _cfg(mcfg, fit_frames_per_clip=fpc)
+        cfg.model.N_ITERS = 2
+        data = Stac(None, cfg, fs.kp_names, setup=fs, verbose=False).fit_offsets(kp)
+        np.savez(f"{tmp}/rank{rank}.npz", offsets=data.offsets, qpos=data.qpos, markers=data.marker_sites)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_offsets_clip_parallel_two_ranks_on_one_gpu(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
+    """The sharded calibration with a real process group (2 ranks sharing cuda:0, gloo): clips split 3 + 2, the
+    3K+2 partial sums all-reduced in fixed rank order; both ranks end with the same offsets and the gathered poses,
+    and they agree with the single-process run (the offset sums associate differently: 1e-6)."""
+    import torch.multiprocessing as mp
+
+    from stac_mjx_amd.stac import Stac
+
+    kp = rodent_mocap[300:310]  # 5 clips of 2
+    cfg = _cfg(rodent_cfg, fit_frames_per_clip=2)
+    cfg.model.N_ITERS = 2
+    one = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False).fit_offsets(kp)
+    port = 29600 + (int(torch.randint(0, 300, (1,)).item()))
+    mp.spawn(_two_rank_fit, args=(port, str(tmp_path), kp, 2), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("offsets", "qpos", "markers"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert r0["qpos"].shape == (10, 74)
+    assert np.abs(r0["offsets"] - one.offsets).max() < 1e-5
+    assert np.abs(r0["markers"] - one.marker_sites).max() < 1e-3
