@@ -348,3 +348,77 @@ def test_lm_single_solve_matches_f64_twin_in_marker_space(rodent_setup, rodent_m
     assert s32["error"] <= 1e-4 and s64["error"] <= 1e-4 and s32["iter_num"] < 40
     m32, m64 = o32.fk(x32)["site_xpos"], o64.fk(x64)["site_xpos"]
     assert np.abs(m32 - m64).max() < 5e-4 and abs(s32["loss"] - s64["loss"]) < 1e-3 * s64["loss"]
+
+
+# ---- the PG driver against an independent transcription of jaxopt's algorithm -----------------------------
+def _pg_numpy(orc, kp, qs, ks, q0, lb, ub, tol, maxiter, maxls):
+    """ProjectedGradient.run as SURVEY.md A2 states it (FISTA momentum, backtracking line search, box projection, unit-step
+    residual), written independently of oracle/stac_oracle.c in numpy float32.  Only the objective (value, gradient) is the
+    oracle's; float32 fma is emulated through float64 (the product of two float32 is exact there), sums use the same
+    pairwise tree as the oracle so that the two drivers can be compared bit for bit."""
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+
+    def tree(v):
+        n = 1
+        while n < v.size:
+            n *= 2
+        v = np.concatenate([v.astype(f32), np.zeros(n - v.size, f32)])
+        while v.size > 1:
+            v = v[0::2] + v[1::2]
+        return f32(v[0])
+
+    def fun(p, grad):
+        loss, g = orc.q_loss(p, kp, qs, ks, q0, grad)
+        return f32(loss), g
+
+    clip = lambda v: np.minimum(np.maximum(v, lb), ub).astype(f32)
+    x, y = q0.astype(f32).copy(), q0.astype(f32).copy()
+    eta_state, t, error = f32(1), f32(1), f32(np.inf)
+    it = ls_evals = 0
+    eps = f32(1.1920929e-7)
+    while it < maxiter and (it == 0 or error > f32(tol)):
+        fy, g = fun(y, True)
+        eta = eta_state
+        cand = clip(fma(-eta, g, y))
+        n = 0
+        while n < maxls:
+            fc, _ = fun(cand, False)
+            ls_evals += 1
+            d = cand - y
+            sq, vd = tree(d * d), tree(d * g)
+            if not (eta * (fc - fy) > (eta * vd + f32(0.5) * sq) + eps):
+                break
+            eta = eta * f32(0.5)
+            cand = clip(fma(-eta, g, y))
+            n += 1
+        eta_next = f32(1) if eta <= f32(1e-6) else eta / f32(0.5)
+        tn = f32(0.5) * (f32(1) + np.sqrt(f32(1) + f32(4) * t * t, dtype=f32))
+        beta = (t - f32(1)) / tn
+        y = fma(beta, cand - x, cand)
+        x = cand
+        _, gn = fun(x, True)
+        d = clip(x - gn) - x
+        error = np.sqrt(tree(d * d), dtype=f32)
+        eta_state, t = eta_next, tn
+        it += 1
+    return x, dict(iter_num=it, stepsize=float(eta_state), error=float(error), t=float(t), ls_evals=ls_evals)
+
+
+@pytest.mark.parametrize("which,maxls", [("all", 15), ("part", 15), ("root", 15), ("all", 2)])
+def test_pg_driver_equals_independent_transcription(orc, rodent_setup, rodent_mocap, which, maxls):
+    fs = rodent_setup
+    o = Oracle(fs.tables, tol=1e-4, maxiter=30, maxls=maxls)
+    kp = rodent_mocap[7]
+    q0 = fs.tables.qpos0.copy()
+    q0[:3] = kp[3 * fs.root_kp_idx: 3 * fs.root_kp_idx + 3]
+    qs = {"all": np.ones(74, bool), "part": fs.part_masks[0].astype(bool), "root": np.arange(74) < 7}[which]
+    ks = np.repeat(fs.trunk_kps, 3).astype(bool) if which == "root" else np.ones(69, bool)
+    x_c, st_c = o.q_opt(kp, qs, ks, q0, fs.lb, fs.ub)
+    x_p, st_p = _pg_numpy(o, kp, qs, ks, q0, fs.lb.astype(np.float32), fs.ub.astype(np.float32), 1e-4, 30, maxls)
+    np.testing.assert_array_equal(x_c, x_p)
+    for k in ("iter_num", "stepsize", "error", "t", "ls_evals"):
+        assert st_c[k] == st_p[k], (k, st_c[k], st_p[k])
+    assert st_c["iter_num"] > 3
