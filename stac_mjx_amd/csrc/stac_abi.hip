@@ -236,15 +236,32 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         v.resize(padded, 0.f);
         return put_raw(v.data(), v.size());
     };
+    // Which body transforms go to LDS: those a site or a child on ANOTHER lane reads back (a child at its parent's
+    // position continues from the lane's registers).  Levels wider than the narrowest lane group (4) can take
+    // several passes per level, where nothing is carried: then every transform is stored.
+    int max_width0 = 0;
+    for (int l = 0; l < nlev; ++l) max_width0 = std::max(max_width0, lev_adr[l + 1] - lev_adr[l]);
+    std::vector<int> stored(nab, max_width0 > 4 ? 1 : 0), xf(nab, -1);
+    stored[0] = 1;  // moments are taken about the first active body
+    for (int k = 0; k < K; ++k) stored[slot_of[t->site_bodyid[k]]] = 1;
+    for (int s = 0; s < nab; ++s) {
+        const int b = slots[s], pb = t->body_parentid[b];
+        if (pb > 0 && pos_in_level[pb] != pos_in_level[b]) stored[slot_of[pb]] = 1;
+    }
+    int nst = 0;
+    for (int s = 0; s < nab; ++s)
+        if (stored[s]) xf[s] = ++nst;  // transform index; 0 = world
     std::vector<BodyRec> brec(nab);
     for (int s = 0; s < nab; ++s) {
         const int b = slots[s];
         BodyRec &r = brec[s];
-        r.parent = ab_parent[s]; r.jadr = ab_jadr[s]; r.jnum = ab_jnum[s];
+        const int pb = t->body_parentid[b];
+        r.parent = pb == 0 ? 0 : std::max(xf[slot_of[pb]], 0);  // transform index (only read when the parent is stored)
+        r.jadr = ab_jadr[s]; r.jnum = ab_jnum[s];
         const float *q = t->body_quat + 4 * b;
         r.flags = (q[0] == 1.0f && q[1] == 0.0f && q[2] == 0.0f && q[3] == 0.0f) ? 1 : 0;
-        const int pb = t->body_parentid[b];
         if (pb > 0 && pos_in_level[pb] == pos_in_level[b]) r.flags |= 2;  // parent transform is in the lane's registers
+        r.flags |= (xf[s] < 0 ? 0xFFFF : xf[s]) << 16;                    // where this body's transform is stored
         for (int i = 0; i < 3; ++i) r.pos[i] = t->body_pos[3 * b + i];
         r.jzero = 0;
         for (int jj = 0; jj < ab_jnum[s] && jj < 31; ++jj) {
@@ -254,16 +271,21 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         for (int i = 0; i < 4; ++i) r.quat[i] = q[i];
     }
     std::vector<JointRec> jrec(std::max(naj, 1));
+    int nqj = 0;
     for (int j = 0; j < naj; ++j) {
         JointRec &r = jrec[j];
         r.type = aj_type[j]; r.qadr = aj_qadr[j]; r.slo = aj_slo[j]; r.shi = aj_shi[j];
         for (int i = 0; i < 3; ++i) { r.pos[i] = aj_pos[3 * j + i]; r.axis[i] = aj_axis[3 * j + i]; }
         r.q0 = aj_q0[j]; r.slot = aj_slot[j];
+        if (aj_type[j] == STAC_JNT_FREE || aj_type[j] == STAC_JNT_BALL) {  // no reference angle: the ordinal among the
+            const int32_t qi = nqj++;                                       // quaternion joints (saved-quaternion slot)
+            std::memcpy(&r.q0, &qi, 4);
+        }
     }
     std::vector<SiteRec> srec(K);
     for (int k = 0; k < K; ++k) {
         for (int i = 0; i < 3; ++i) srec[k].pos[i] = t->site_pos[3 * k + i];
-        srec[k].slot_sortpos = slot_of[t->site_bodyid[k]] | (sortpos[k] << 16);
+        srec[k].slot_sortpos = xf[slot_of[t->site_bodyid[k]]] | (sortpos[k] << 16);
     }
     h.off_lev_adr = put_raw(lev_adr.data(), lev_adr.size());
     h.off_body = put_raw(brec.data(), brec.size() * sizeof(BodyRec) / 4);
@@ -299,7 +321,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                         fl |= FK_BODY;
                         if (!(brec[s].flags & 2)) fl |= FK_PARENT_LDS;
                         if (!(brec[s].flags & 1)) fl |= FK_BQUAT;
-                        r[1] = ab_parent[s];
+                        r[1] = brec[s].parent;
                         for (int c = 0; c < 3; ++c) r[4 + c] = f2i(brec[s].pos[c]);
                         if (rw == 16) for (int c = 0; c < 4; ++c) r[12 + c] = f2i(brec[s].quat[c]);
                     }
@@ -311,9 +333,9 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                         for (int c = 0; c < 3; ++c) r[8 + c] = f2i(aj_pos[3 * j + c]);
                         r[11] = aj_qadr[j];
                     }
-                    if (i == nsteps - 1) fl |= FK_LAST;
+                    if (i == nsteps - 1 && xf[s] >= 0) fl |= FK_LAST;
                     r[0] = fl;
-                    r[7] = s + 1;
+                    r[7] = std::max(xf[s], 0);
                 }
             }
         for (int ml = 0; ml + 1 < n_mlev; ++ml)
@@ -329,15 +351,19 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
 
     // per-chain LDS layout
     int o = 0;
-    h.c_bx = o; o += (nab + 1) * 7;
+    h.nst = nst;
+    h.nqj = nqj;
+    h.c_bx = o; o += (nst + 1) * 7;
     h.c_ja = o; o += naj * 7;
     h.c_jn = o; o += naj;
+    h.c_qsv = o; o += 4 * nqj;
     o = (o + 3) & ~3;
-    h.c_sw = o; o += K * 6;
+    h.c_sw = o; o += std::max(K * 6, h.nqpad);
     o = (o + 3) & ~3;
     h.c_gg = o; o += std::max(h.nqpad, (K + 3) & ~3);
     o = (o + 3) & ~3;
-    h.c_qe = o; o += h.nqpad;
+    h.c_qe = h.c_sw;  // the evaluation point is dead once the site pass writes the wrenches (the LM kernel, which reads it
+                      // later in the trip, moves it into its own region)
     h.c_kp = o; o += 3 * K;
     // odd stride (mod 32 banks) so that the chains of one wavefront hit different LDS banks
     if ((o & 1) == 0) o += 1;
@@ -680,6 +706,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     L.lambda0 = lambda0 > 0.0f ? lambda0 : 1e-2f;
     int o = h.chain_stride;
     o = (o + 3) & ~3;
+    L.c_qe = o; o += h.nqpad;  // the LM kernel reads the evaluation point after the site pass: not aliased
     L.c_sx = o; o += 3 * h.K;
     o = (o + 3) & ~3;
     L.c_jp = o; o += std::max(h.K * L.maxpd * 3, L.npk);
@@ -701,6 +728,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     a.hdr = nullptr;
     a.plan = m->d_blob;
     a.h = m->h;  // total_words (what the launch stages in LDS) is settled with the launch shape below
+    a.h.c_qe = m->lm_args.c_qe;
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const LmArgs &L = m->lm_args;
 #ifdef STAC_PROFILE

@@ -154,7 +154,7 @@ __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
 __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf) {
     const float *jrec = P + H.off_joint;
-    float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *qlb = CBc + H.c_ja + 3;
+    float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *qlb = CBc + H.c_ja + 3, *qsv = CBc + H.c_qsv;
     for (int j = lf; j < H.naj; j += gf) {
         const float *jr = jrec + 12 * j;
         const int4 ji = lds4i(jr);  // type, qadr, slo, shi
@@ -176,6 +176,8 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
             st4(qe + qa, qn);  // written back, like MJX
             st4(qlb + 7 * j, qn);
             jn[j] = n;
+            // the gradient pass needs it after qe's region has been reused: q0 of a quaternion joint is its ordinal
+            st4(qsv + 4 * __builtin_bit_cast(int, lds4(jr + 4).w), qn);
         }
     }
 }
@@ -247,8 +249,11 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
                     st4(ja + 7 * j + 3, prequat);
                 }
             }
-            st3(bx + (s + 1) * 7, pos);
-            st4(bx + (s + 1) * 7 + 3, quat);
+            const int xf = (int)((unsigned)bi.w >> 16);
+            if (xf != 0xFFFF) {  // somebody reads it back (a site, or a child on another lane)
+                st3(bx + xf * 7, pos);
+                st4(bx + xf * 7 + 3, quat);
+            }
             cpos = pos;
             cquat = quat;
         }

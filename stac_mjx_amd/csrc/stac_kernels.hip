@@ -70,7 +70,7 @@ void q_phase_kernel(const QArgs a) {
         MB[i] = bits;
     }
     float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
-    float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn;
+    float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn, *qsv = CB + H.c_qsv;
     float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
     float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
     __syncthreads();  // the only workgroup-wide barrier: the plan is shared by the block's waves
@@ -176,7 +176,7 @@ void q_phase_kernel(const QArgs a) {
         for (int k = lg; k < K; k += G) {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
-            const float *bp = bx + ((ss & 0xFFFF) + 1) * 7;
+            const float *bp = bx + (ss & 0xFFFF) * 7;
             const V3 sx = add3(ld3(bp), rotate(V3{sr.x, sr.y, sr.z}, ld4(bp + 3)));
             float w0, w1, w2;
             if (a.single) {
@@ -278,7 +278,7 @@ void q_phase_kernel(const QArgs a) {
                     } else {
                         tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});
                     }
-                    const Q4 qh = ld4(qe + qa);
+                    const Q4 qh = ld4(qsv + 4 * __builtin_bit_cast(int, lds4(jr + 4).w));  // saved by the pre-pass
                     const V3 u = {qh.x, qh.y, qh.z};
                     const V3 uxt = cross3(u, tl);
                     const float n = jn[j];

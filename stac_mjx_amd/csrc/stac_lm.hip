@@ -165,7 +165,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
         for (int k = lg; k < K; k += G) {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
-            const float *bp = bx + ((ss & 0xFFFF) + 1) * 7;
+            const float *bp = bx + (ss & 0xFFFF) * 7;
             const V3 sx = add3(ld3(bp), rotate(V3{sr.x, sr.y, sr.z}, ld4(bp + 3)));
             const float w = trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f;
             const float rx = (kpl[3 * k] - sx.x) * w, ry = (kpl[3 * k + 1] - sx.y) * w, rz = (kpl[3 * k + 2] - sx.z) * w;

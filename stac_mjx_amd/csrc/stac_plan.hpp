@@ -13,12 +13,13 @@ constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 
 // Records are 16-byte aligned so the kernel fetches them with ds_read_b128.
 struct BodyRec {      // 12 words
-    int32_t parent;   // index into the per-chain transform array: 0 = world, s+1 = slot s
+    int32_t parent;   // transform index of the parent in the per-chain array bx: 0 = world
     int32_t jadr;     // first joint record
     int32_t jnum;
     int32_t flags;    // bit 0: body_quat is the identity (product with it is exact, skipped)
                       // bit 1: the parent sits at the same position of the previous level (its transform is still
                       //        in the registers of the lane that now takes this body)
+                      // bits 16-31: transform index this body is stored at (0xFFFF: nobody reads it back: not stored)
     float pos[3];
     int32_t jzero;    // bit i: joint i of the body has jnt_pos == 0 (rotate(0, q) = 0: anchor = pos, exact)
     float quat[4];
@@ -29,7 +30,7 @@ struct JointRec {     // 12 words
     int32_t slo;      // sorted-site range [slo, shi) of the joint's body subtree
     int32_t shi;
     float pos[3];
-    float q0;         // qpos0[qadr] (hinge / slide reference)
+    float q0;         // qpos0[qadr] (hinge / slide reference); free / ball: int32 ordinal among the quaternion joints
     float axis[3];
     int32_t slot;     // body slot
 };
@@ -39,11 +40,11 @@ struct JointRec {     // 12 words
 // make every address a function of the loop counter, so the kernel fetches step k+1 while it computes step k.
 struct FkStep {       // 12 words (+4 when some active body has a non-identity body_quat)
     int32_t flags;    // FK_* bits; 0 = nothing to do at this position
-    int32_t parent;   // transform index of the parent (0 = world, s+1 = slot s)            [FK_BODY]
+    int32_t parent;   // transform index of the parent (0 = world)                             [FK_BODY]
     int32_t j;        // active joint index                                                   [FK_JOINT]
     int32_t jnext;    // joint index of this position's next step (its ql is fetched one step ahead), else 0
     float bpos[3];    // body_pos                                                             [FK_BODY]
-    int32_t xf;       // transform index this body is stored at (slot + 1)
+    int32_t xf;       // transform index this body is stored at (FK_LAST is only set for stored bodies)
     float jpos[3];    // jnt_pos                                                              [FK_JOINT]
     int32_t qadr;     // qpos address                                                         [FK_JOINT]
     // float bquat[4] follows when PlanHeader::fk_rec_words == 16
@@ -60,7 +61,7 @@ enum : int32_t {
 
 struct SiteRec {      // 4 words
     float pos[3];     // the marker offset -- mutable (stac_set_site_pos writes the blob)
-    int32_t slot_sortpos;  // body slot | sorted position << 16
+    int32_t slot_sortpos;  // transform index of the site's body | sorted position << 16
 };
 
 struct PlanHeader {
@@ -83,15 +84,18 @@ struct PlanHeader {
     int32_t total_words;   // words a launch stages in LDS (the per-launch copy may stop at core_words)
     int32_t core_words;    // blob without the FK program (the program is last)
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
-    int32_t c_bx;      // [(nab+1)*7] pos(3) quat(4); entry 0 = world
+    int32_t c_bx;      // [(nst+1)*7] pos(3) quat(4) of the stored bodies; entry 0 = world
     int32_t c_ja;      // [naj*7] anchor(3) + quaternion before the joint(4) (the joint pass rotates the axis)
     int32_t c_jn;      // [nquat_active] |q| of free/ball quaternions, indexed by JointRec order of quaternion joints
     int32_t c_sw;      // [K*6] site wrench f(3) t(3), by sorted-site position
     int32_t c_gg;      // [nqpad] gradient out; aliased by r2[K] (per-site loss terms, consumed earlier)
-    int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place)
+    int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place); aliases c_sw in the PG kernel
     int32_t c_kp;      // [3K] keypoints of the current frame
     int32_t chain_stride;
     int32_t max_width; // bodies in the widest level
+    int32_t nst;       // bodies whose transform is stored in LDS (a site or a child on another lane reads it)
+    int32_t nqj;       // active quaternion joints (free / ball)
+    int32_t c_qsv;     // [4*nqj] their normalised quaternions, kept for the gradient pass
     int32_t off_fkstep;    // FkStep[n_mlev * max_width] (word offset into the blob)
     int32_t n_mlev;        // micro-levels of the FK program
     int32_t fk_rec_words;  // 12, or 16 when the records carry body_quat
@@ -161,6 +165,7 @@ struct LmArgs {
     int32_t maxpd;         // max over kinds
     float lambda0;
     // extra per-chain LDS regions (float offsets inside the chain region, after the PG layout)
+    int32_t c_qe;          // [nqpad] evaluation point (overrides PlanHeader::c_qe for this kernel)
     int32_t c_sx;          // [3K] site world positions by sorted-site position
     int32_t c_jp;          // [K * maxpd * 3] weighted Jacobian blocks; aliased by the factor H[npk]
     int32_t c_A;           // [npk] J^T W J (+ gauge term), row b holds its root-path columns: A[b * maxpd + pd(a)]
