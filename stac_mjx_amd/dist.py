@@ -30,6 +30,12 @@ def world() -> tuple[int, int]:
     return 0, 1
 
 
+def barrier() -> None:
+    """No-op without a process group."""
+    if is_dist():
+        tdist.barrier()
+
+
 def shard_range(n_items: int, rank: int | None = None, world_size: int | None = None) -> tuple[int, int]:
     """Contiguous block [lo, hi) of ``n_items`` clips owned by ``rank`` (earlier ranks get the remainder)."""
     r, w = world()

@@ -121,6 +121,14 @@ def load_data(cfg, base_path: Path | None = None):
 _DATASETS = ("kp_data", "marker_sites", "offsets", "qpos", "qvel", "xpos", "xquat")
 
 
+def resolve_output_path(file_path) -> Path:
+    """The path ``save_data_to_h5`` writes for ``file_path``: itself with h5py, else its ``.npz`` stand-in."""
+    file_path = Path(file_path)
+    if h5py is not None and file_path.suffix in (".h5", ".hdf5"):
+        return file_path
+    return file_path.with_suffix(".npz")
+
+
 def save_data_to_h5(config, kp_names, names_qpos, names_xpos, kp_data, marker_sites, offsets, qpos,
                     xpos, xquat, qvel, file_path) -> Path:  # fmt: skip
     """Write the reference's output contract (io.py:194-237).  Returns the path actually written."""

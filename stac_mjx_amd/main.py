@@ -7,7 +7,7 @@ from pathlib import Path
 
 import numpy as np
 
-from . import io, utils
+from . import dist, io, utils
 from .config import compose_config
 from .stac import Stac
 
@@ -44,7 +44,10 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
         kps = kp_data[: cfg.stac.n_fit_frames]
         print(f"Running fit. Mocap data shape: {kps.shape}")
         fit_data = stac.fit_offsets(kps)
-        fit_offsets_path = io.save_data_to_h5(config=cfg, file_path=fit_offsets_path, **fit_data.as_dict())
+        if dist.world()[0] == 0:  # multi-GPU: every rank holds the same result, rank 0 writes it
+            io.save_data_to_h5(config=cfg, file_path=fit_offsets_path, **fit_data.as_dict())
+        fit_offsets_path = io.resolve_output_path(fit_offsets_path)
+        dist.barrier()
         print(f"saved fit to {fit_offsets_path}", flush=True)
     else:
         print("Skipping fit_offsets. To change this behavior, set cfg.stac.skip_fit_offsets to False.")
@@ -66,6 +69,9 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
         batched = ik_data.qpos.reshape((-1, cfg.stac.n_frames_per_clip, ik_data.qpos.shape[-1]))
         qvels = [utils.compute_velocity_from_kinematics(c, dt=stac._timestep, freejoint=stac._freejoint) for c in batched]
         ik_data.qvel = np.stack(qvels).reshape(-1, qvels[0].shape[-1])
-    ik_only_path = io.save_data_to_h5(config=cfg, file_path=ik_only_path, **ik_data.as_dict())
+    if dist.world()[0] == 0:
+        io.save_data_to_h5(config=cfg, file_path=ik_only_path, **ik_data.as_dict())
+    ik_only_path = io.resolve_output_path(ik_only_path)
+    dist.barrier()
     print(f"Saved ik_only to {ik_only_path}. Finished in {(time.time() - start) / 60:.2f} minutes")
     return fit_offsets_path, ik_only_path
