@@ -419,3 +419,124 @@ def test_lm_q_phase_matches_oracle_lm_in_marker_space(rodent_setup, rodent_mocap
     np.testing.assert_allclose(_np(fk["site_xpos"]), mk.reshape(-1, 23, 3), atol=3e-7, rtol=0)
     it = _np(res["counters"])[..., 0].mean()
     assert it < 60, it
+
+
+# ---- random models: the plan builder (levels, positions, stored transforms, step program) on arbitrary trees ------------
+def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_bias=0.6):
+    """A random kinematic tree as ModelTables: depth-first body order, 0-3 joints per body (mostly hinges, some with
+    jnt_pos == 0, some slides / balls), random body orientations (some identity), sites on random bodies."""
+    from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE, JNT_HINGE, JNT_SLIDE, ModelTables
+
+    parent = [0] * nbody
+    for b in range(2, nbody):  # b = 1 is the root body under the world
+        # depth-first numbering: the parent must be on the path from the root to body b - 1
+        path = [b - 1]
+        while path[-1] > 1:
+            path.append(parent[path[-1]])
+        parent[b] = path[0] if rng.random() < max_children_bias else int(rng.choice(path))
+    parent[1] = 0
+    depth = [0] * nbody
+    for b in range(1, nbody):
+        depth[b] = depth[parent[b]] + 1
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    body_pos = rng.normal(0, 0.05, (nbody, 3))
+    body_quat = np.tile([1.0, 0, 0, 0], (nbody, 1))
+    for b in range(1, nbody):
+        if rng.random() < 0.4:
+            body_quat[b] = unit(rng.normal(0, 1, 4))
+    jt, jadr_q, jbody, jpos, jaxis, jrange, qpos0 = [], [], [], [], [], [], []
+    body_jntadr, body_jntnum = [-1] * nbody, [0] * nbody
+    nq = 0
+    for b in range(1, nbody):
+        n = 1 if (b == 1 and free_root) else int(rng.choice([0, 1, 1, 1, 2, 3]))
+        if n:
+            body_jntadr[b] = len(jt)
+        body_jntnum[b] = n
+        for i in range(n):
+            if b == 1 and free_root:
+                ty = JNT_FREE
+            else:
+                u = rng.random()
+                ty = JNT_SLIDE if u < p_slide else (JNT_BALL if u < p_slide + p_ball else JNT_HINGE)
+            jt.append(ty)
+            jadr_q.append(nq)
+            jbody.append(b)
+            jpos.append(np.zeros(3) if rng.random() < 0.4 else rng.normal(0, 0.02, 3))
+            jaxis.append(unit(rng.normal(0, 1, 3)) if rng.random() < 0.5 else np.eye(3)[rng.integers(3)])
+            if ty == JNT_FREE:
+                qpos0 += [0, 0, 0.1, 1, 0, 0, 0]
+                jrange.append([0, 0])
+                nq += 7
+            elif ty == JNT_BALL:
+                qpos0 += [1, 0, 0, 0]
+                jrange.append([0, 0])
+                nq += 4
+            else:
+                qpos0.append(float(rng.normal(0, 0.05)) if rng.random() < 0.3 else 0.0)
+                jrange.append([-1.0, 1.2] if ty == JNT_HINGE else [-0.05, 0.05])
+                nq += 1
+    K = int(rng.integers(3, 12))
+    site_body = np.sort(rng.integers(1, nbody, K)).astype(np.int32)
+    return ModelTables(
+        nbody=nbody, njnt=len(jt), nq=nq, nsite=K, body_parentid=np.array(parent, np.int32),
+        body_pos=body_pos.astype(np.float32), body_quat=body_quat.astype(np.float32),
+        body_jntadr=np.array(body_jntadr, np.int32), body_jntnum=np.array(body_jntnum, np.int32),
+        body_depth=np.array(depth, np.int32), jnt_type=np.array(jt, np.int32), jnt_qposadr=np.array(jadr_q, np.int32),
+        jnt_bodyid=np.array(jbody, np.int32), jnt_pos=np.array(jpos, np.float32).reshape(-1, 3),
+        jnt_axis=np.array(jaxis, np.float32).reshape(-1, 3), jnt_range=np.array(jrange, np.float32).reshape(-1, 2),
+        qpos0=np.array(qpos0, np.float32), site_bodyid=site_body, site_pos=rng.normal(0, 0.01, (K, 3)).astype(np.float32),
+        body_names=[f"b{i}" for i in range(nbody)], jnt_names=[f"j{i}" for i in range(len(jt))],
+        site_names=[f"s{i}" for i in range(K)])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_bit_exact(seed):
+    """Random trees (3-40 bodies, chains and bushes, free or fixed root, slides, every third one with ball joints)
+    through FK and the q_phase at several lane-group sizes: HIP == oracle bit for bit."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE, JNT_QPOS_DIMS
+
+    rng = np.random.default_rng(1000 + seed)
+    free_root = bool(seed % 2)
+    t = _random_tables(rng, int(rng.integers(3, 41)), free_root, p_ball=0.15 if seed % 3 == 0 else 0.0,
+                       max_children_bias=float(rng.choice([0.3, 0.6, 0.9])))
+    nq, K = t.nq, t.nsite
+    if nq == 0:
+        pytest.skip("no joints drawn")
+    lb, ub = np.full(nq, -np.inf, np.float32), np.full(nq, np.inf, np.float32)
+    for j in range(t.njnt):
+        a, ty = int(t.jnt_qposadr[j]), int(t.jnt_type[j])
+        if ty == JNT_FREE:
+            lb[a + 3:a + 7], ub[a + 3:a + 7] = -1, 1
+        elif ty == JNT_BALL:
+            lb[a:a + 4], ub[a:a + 4] = -1, 1
+        else:
+            lb[a], ub[a] = min(t.jnt_range[j, 0], 0.0), t.jnt_range[j, 1]
+    orc = Oracle(t, tol=1e-5, maxiter=12)
+    # poses inside the box, quaternions deliberately not normalised
+    q = np.tile(t.qpos0, (6, 1)) + rng.normal(0, 0.2, (6, nq)).astype(np.float32)
+    q = np.clip(q, np.where(np.isfinite(lb), lb, -3), np.where(np.isfinite(ub), ub, 3)).astype(np.float32)
+    kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32)
+    kp = (kp + rng.normal(0, 2e-3, kp.shape)).astype(np.float32).reshape(3, 2, 3 * K)
+    # two part groups: a random half of the coordinates, and the coordinates of one random joint
+    part = np.zeros((2, nq), np.uint8)
+    part[0] = rng.random(nq) < 0.5
+    jr = int(rng.integers(t.njnt))
+    part[1, int(t.jnt_qposadr[jr]):int(t.jnt_qposadr[jr]) + JNT_QPOS_DIMS[int(t.jnt_type[jr])]] = 1
+    trunk = (rng.random(K) < 0.6).astype(np.uint8)
+    trunk[0] = 1
+    do_root = free_root
+    ref = orc.ik_clips(kp, lb, ub, part, trunk, 0, 7, do_root_opt=do_root)
+    for lanes in (4, 16, 0):
+        eng = Engine(t, lb, ub, tol=1e-5, maxiter=12, lanes_per_chain=lanes)
+        fk = eng.fk(q)
+        for i in range(len(q)):
+            o = orc.fk(q[i].copy())
+            np.testing.assert_array_equal(_np(fk["xpos"][i]), o["xpos"])
+            np.testing.assert_array_equal(_np(fk["site_xpos"][i]), o["site_xpos"])
+        res = eng.q_phase(kp, part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=do_root)
+        _compare_phase(res, ref)
