@@ -89,6 +89,28 @@ def test_q_solve_bit_exact(rodent_setup, rodent_mocap, lanes, which):
         assert np.abs(params[n] - x).max() <= TOL_NORTH_STAR
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_q_solve_random_masks_bit_exact(rodent_setup, rodent_mocap, seed):
+    """Random qs_to_opt / per-coordinate kps_to_opt masks (incl. nothing to optimise and no keypoint weighted), random
+    solver settings and starting points: the StacCore.q_opt seam equals the oracle bit for bit."""
+    fs = rodent_setup
+    rng = np.random.default_rng(seed)
+    tol, maxiter, maxls = float(rng.choice([1e-3, 1e-5])), int(rng.integers(1, 25)), int(rng.choice([2, 5, 15]))
+    eng, orc = _engine(fs, tol=tol, maxiter=maxiter, maxls=maxls), _oracle(fs, tol=tol, maxiter=maxiter, maxls=maxls)
+    N = 3
+    kp = rodent_mocap[rng.integers(0, 900):][:N]
+    q0 = np.repeat(fs.tables.qpos0[None], N, 0) + rng.normal(0, 0.05, (N, 74)).astype(np.float32)
+    q0[:, :3] = kp[:, 3 * fs.root_kp_idx: 3 * fs.root_kp_idx + 3]
+    qs = rng.random(74) < rng.choice([0.0, 0.1, 0.5, 1.0])
+    ks = rng.random(69) < rng.choice([0.0, 0.3, 1.0])
+    params, state, counters = (_np(v) for v in eng.q_solve(kp, q0, qs, ks))
+    for n in range(N):
+        x, st = orc.q_opt(kp[n], qs, ks, q0[n], fs.lb, fs.ub)
+        assert counters[n].tolist() == [st["iter_num"], st["ls_evals"], st["grad_evals"], 1]
+        np.testing.assert_array_equal(params[n], x)
+        np.testing.assert_array_equal(state[n], np.array([st["error"], st["stepsize"], st["t"], st["loss"]], np.float32))
+
+
 # ---- the q_phase drivers ---------------------------------------------------------------------------------
 def _compare_phase(res, ref, bodies=True):
     np.testing.assert_array_equal(_np(res["counters"]).astype(np.uint32), ref["counters"])
