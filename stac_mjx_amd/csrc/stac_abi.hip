@@ -219,6 +219,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     m->h_ab_parent = ab_parent; m->h_aj_type = aj_type; m->h_aj_qadr = aj_qadr; m->h_aj_slot = aj_slot;
     m->h_aj_slo = aj_slo; m->h_aj_shi = aj_shi; m->h_sortpos = sortpos;
     if (nab >= 65535 || K >= 65535) return fail(STAC_ERR_CAPACITY, "too many bodies / sites");
+    if (K > 64) return fail(STAC_ERR_CAPACITY, "more than 64 fit sites: the kernels' in-register loss tree holds 16 float4");
 
     std::vector<float> &B = m->blob_host;
     B.clear();

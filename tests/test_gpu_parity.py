@@ -408,6 +408,15 @@ def test_errors_are_loud(rodent_setup):
         eng.q_phase(np.zeros((1, 1, 69), np.float32), part_masks=[])
     with pytest.raises(ValueError):
         _engine(fs).q_phase(np.zeros((1, 1, 68), np.float32), part_masks=[])
+    # capacity limits are errors, never silent truncation: > 64 fit sites do not fit the in-register loss tree
+    big = fs.tables.copy()
+    big.nsite = 65
+    big.site_bodyid = np.resize(fs.tables.site_bodyid, 65).astype(np.int32)
+    big.site_pos = np.resize(fs.tables.site_pos, (65, 3)).astype(np.float32)
+    from stac_mjx_amd.engine import Engine
+
+    with pytest.raises(StacHipError, match="64 fit sites"):
+        Engine(big, fs.lb, fs.ub)
 
 
 # ---- optional LM solver (STAC_SOLVER_LM; not the reference's algorithm) vs its oracle statement ---------------------------------
