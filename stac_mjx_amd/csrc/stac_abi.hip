@@ -219,7 +219,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     m->h_ab_parent = ab_parent; m->h_aj_type = aj_type; m->h_aj_qadr = aj_qadr; m->h_aj_slot = aj_slot;
     m->h_aj_slo = aj_slo; m->h_aj_shi = aj_shi; m->h_sortpos = sortpos;
     if (nab >= 65535 || K >= 65535) return fail(STAC_ERR_CAPACITY, "too many bodies / sites");
-    if (K > 64) return fail(STAC_ERR_CAPACITY, "more than 64 fit sites: the kernels' in-register loss tree holds 16 float4");
+    if (K > 4096) return fail(STAC_ERR_CAPACITY, "more than 4096 fit sites");
 
     std::vector<float> &B = m->blob_host;
     B.clear();
@@ -361,7 +361,9 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     o = (o + 3) & ~3;
     h.c_sw = o; o += std::max(K * 6, h.nqpad);
     o = (o + 3) & ~3;
-    h.c_gg = o; o += std::max(h.nqpad, (K + 3) & ~3);
+    h.kpow2 = 1;
+    while (h.kpow2 < K) h.kpow2 <<= 1;
+    h.c_gg = o; o += std::max(h.nqpad, K > 64 ? h.kpow2 : ((K + 3) & ~3));
     o = (o + 3) & ~3;
     h.c_qe = h.c_sw;  // the evaluation point is dead once the site pass writes the wrenches (the LM kernel, which reads it
                       // later in the trip, moves it into its own region)

@@ -172,7 +172,7 @@ void q_phase_kernel(const QArgs a) {
         const V3 cref = ld3(bx + 7);  // slot 0 = first active body (the root): moments are taken about it
         const bool trunk_w = (!a.single) && kind < 2;
         const int Kpad = (K + 3) & ~3;
-        for (int k = K + lg; k < Kpad; k += G) r2[k] = 0.0f;  // zero padding of the loss tree
+        for (int k = K + lg; k < (K > 64 ? H.kpow2 : Kpad); k += G) r2[k] = 0.0f;  // zero padding of the loss tree
         for (int k = lg; k < K; k += G) {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
@@ -202,7 +202,14 @@ void q_phase_kernel(const QArgs a) {
         float loss;
         {
             const int n4 = Kpad >> 2;
-            if (n4 <= 8) {
+            if (n4 > 16) {
+                // more than 64 sites: the same pairwise tree, in place in LDS (r2 is padded to a power of two)
+                for (int h = 1; h < H.kpow2; h <<= 1) {
+                    for (int i = lg * 2 * h; i < H.kpow2; i += G * 2 * h) r2[i] = r2[i] + r2[i + h];
+                    wave_sync();
+                }
+                loss = r2[0];
+            } else if (n4 <= 8) {
                 float acc[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {

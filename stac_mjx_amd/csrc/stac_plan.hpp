@@ -95,6 +95,7 @@ struct PlanHeader {
     int32_t max_width; // bodies in the widest level
     int32_t nst;       // bodies whose transform is stored in LDS (a site or a child on another lane reads it)
     int32_t nqj;       // active quaternion joints (free / ball)
+    int32_t kpow2;     // K rounded up to a power of two (the LDS loss tree of models with more than 64 sites)
     int32_t c_qsv;     // [4*nqj] their normalised quaternions, kept for the gradient pass
     int32_t off_fkstep;    // FkStep[n_mlev * max_width] (word offset into the blob)
     int32_t n_mlev;        // micro-levels of the FK program

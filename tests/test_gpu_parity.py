@@ -408,15 +408,30 @@ def test_errors_are_loud(rodent_setup):
         eng.q_phase(np.zeros((1, 1, 69), np.float32), part_masks=[])
     with pytest.raises(ValueError):
         _engine(fs).q_phase(np.zeros((1, 1, 68), np.float32), part_masks=[])
-    # capacity limits are errors, never silent truncation: > 64 fit sites do not fit the in-register loss tree
-    big = fs.tables.copy()
-    big.nsite = 65
-    big.site_bodyid = np.resize(fs.tables.site_bodyid, 65).astype(np.int32)
-    big.site_pos = np.resize(fs.tables.site_pos, (65, 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("lanes", [0, 16])
+def test_more_than_64_sites(rodent_setup, lanes):
+    """70 fit sites: the loss tree leaves the registers (pairwise tree in LDS, same order as the oracle's)."""
+    from oracle import Oracle
     from stac_mjx_amd.engine import Engine
 
-    with pytest.raises(StacHipError, match="64 fit sites"):
-        Engine(big, fs.lb, fs.ub)
+    fs = rodent_setup
+    rng = np.random.default_rng(70)
+    t = fs.tables.copy()
+    pick = np.sort(rng.integers(0, 23, 70))
+    t.nsite = 70
+    t.site_bodyid = fs.tables.site_bodyid[pick].astype(np.int32)
+    t.site_pos = (fs.tables.site_pos[pick] + rng.normal(0, 2e-3, (70, 3))).astype(np.float32)
+    t.site_names = [f"s{i}" for i in range(70)]
+    orc = Oracle(t, tol=1e-4, maxiter=15)
+    q = np.tile(t.qpos0, (4, 1)) + rng.normal(0, 0.05, (4, 74)).astype(np.float32)
+    kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32).reshape(2, 2, 210)
+    kp = (kp + rng.normal(0, 1e-3, kp.shape)).astype(np.float32)
+    trunk = (rng.random(70) < 0.4).astype(np.uint8)
+    eng = Engine(t, fs.lb, fs.ub, tol=1e-4, maxiter=15, lanes_per_chain=lanes)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=trunk, root_kp_idx=3, root_dims=7, do_root_opt=True)
+    _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, trunk, 3, 7))
 
 
 # ---- optional LM solver (STAC_SOLVER_LM; not the reference's algorithm) vs its oracle statement ---------------------------------
