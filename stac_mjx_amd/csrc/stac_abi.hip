@@ -577,7 +577,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         if (m->h.max_width <= G && !(getenv("STAC_HIP_FLAGS") && (atoi(getenv("STAC_HIP_FLAGS")) & 2))) {
             PlanHeader hp = m->h;
             const QShape shp = pick_shape(hp, G, nkinds, waves_needed);
-            if (shp.wpb && shp.waves_per_cu >= sh.waves_per_cu) { sh = shp; a.h.total_words = m->h.total_words; a.flags &= ~2; }
+            if (shp.wpb && (shp.waves_per_cu >= sh.waves_per_cu || (long)shp.waves_per_cu * kCus >= waves_needed)) {
+                sh = shp; a.h.total_words = m->h.total_words; a.flags &= ~2;  // same residency, or every wave resident anyway
+            }
         }
         if (const char *w = getenv("STAC_HIP_WPE")) sh.wpe = atoi(w) >= 4 ? 4 : (atoi(w) == 3 && G == 16) ? 3 : 2;
         if (const char *w = getenv("STAC_HIP_WPB")) {  // developer overrides

@@ -159,6 +159,20 @@ def test_q_phase_fk_program_and_level_loop_agree(rodent_setup, fly_setup, rodent
     _compare_phase(resf, orcf.ik_clips(kpf, fly.lb, fly.ub, fly.part_masks, fly.trunk_kps, 0, 7, do_root_opt=False))
 
 
+@pytest.mark.parametrize("wpe,wpb", [("2", "3"), ("3", "10"), ("4", "5"), ("4", "8")])
+def test_q_phase_register_cap_variants(rodent_setup, rodent_mocap, monkeypatch, wpe, wpb):
+    """The 256- / 168- / 128-VGPR builds of the 16-lane kernel (the launch shapes of large batches, forced here on a
+    small one through the developer overrides), multi-wave workgroups with ragged last blocks: all equal the oracle."""
+    monkeypatch.setenv("STAC_HIP_WPE", wpe)
+    monkeypatch.setenv("STAC_HIP_WPB", wpb)
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=16, maxiter=40), _oracle(fs, maxiter=40)
+    kp = rodent_mocap[700:745].reshape(45, 1, 69)  # 45 chains: 12 waves, a partly filled last wave
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims))
+
+
 def test_q_phase_carried_chain_no_root_opt(rodent_setup, rodent_mocap):
     """fit_offsets semantics: one chain continued across calls with q_init (stac.py:298-311)."""
     fs = rodent_setup
