@@ -240,62 +240,69 @@ void q_phase_kernel(const QArgs a) {
         }
         wave_sync();
         PROF_TICK(4);  // loss sum
+        // gradient of one joint of the evaluation whose arrays start at CBx: subtree wrench of the joint's
+        // body = its sites in (body id, site id) order, summed from zero, then the joint formulas
+        auto joint_gradient = [&](const int j, float *CBx) {
+            const float *swx = CBx + H.c_sw, *jax_ = CBx + H.c_ja, *qsvx = CBx + H.c_qsv, *jnx = CBx + H.c_jn;
+            float *ggx = CBx + H.c_gg;
+            const V3 crefx = ld3(CBx + H.c_bx + 7);
+            const float *jr = jrec + 12 * j;
+            const int4 ji = lds4i(jr);  // type, qadr, slo, shi
+            const int ty = ji.x, ad = ji.y;
+            V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
+                int i = ji.z;
+                for (; i + 4 <= ji.w; i += 4) {  // same left-to-right order; four wrenches in flight per LDS round trip
+                    V3 f4[4], t4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { f4[u] = ld3(swx + 6 * (i + u)); t4[u] = ld3(swx + 6 * (i + u) + 3); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { Fs = add3(Fs, f4[u]); T0 = add3(T0, t4[u]); }
+                }
+                for (; i < ji.w; ++i) {
+                    Fs = add3(Fs, ld3(swx + 6 * i));
+                    T0 = add3(T0, ld3(swx + 6 * i + 3));
+                }
+                const V3 anchor = ld3(jax_ + 7 * j);
+                const Q4 prequat = ld4(jax_ + 7 * j + 3);
+                const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
+                if (ty == JHINGE) {
+                    const float4 ja4 = lds4(jr + 8);
+                    ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
+                } else if (ty == JSLIDE) {
+                    const float4 ja4 = lds4(jr + 8);
+                    ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), Fs);
+                } else {
+                    int qa = ad;
+                    V3 tl = tau;
+                    if (ty == JFREE) {
+                        st3(ggx + ad, Fs);
+                        qa = ad + 3;
+                    } else {
+                        tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});
+                    }
+                    const Q4 qh = ld4(qsvx + 4 * __builtin_bit_cast(int, lds4(jr + 4).w));  // saved by the pre-pass
+                    const V3 u = {qh.x, qh.y, qh.z};
+                    const V3 uxt = cross3(u, tl);
+                    const float n = jnx[j];
+                    const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
+                    ggx[qa] = (-2.0f * dot3(tl, u)) / dn;
+                    ggx[qa + 1] = (2.0f * FMA(qh.w, tl.x, -uxt.x)) / dn;
+                    ggx[qa + 2] = (2.0f * FMA(qh.w, tl.y, -uxt.y)) / dn;
+                    ggx[qa + 3] = (2.0f * FMA(qh.w, tl.z, -uxt.z)) / dn;
+                }
+        };
         float gnew[NQR];
 #pragma unroll
         for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
-        if (any_grad) {
+        // (latency mode: a speculative trip computes gradients only for the two evaluations it ends up using, below)
+        if (any_grad && !(SPEC && st_in == ST_SPEC)) {
             // r2 (aliased by gg) has been consumed by the loss sum
             for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
             wave_sync();
             PROF_TICK(5);  // zero gg
             // ---- per-joint gradient: subtree wrench of the joint's body = its sites in
             //      (body id, site id) order, summed from zero, then the joint formulas ---------------------
-            for (int j = lg; j < H.naj; j += G) {
-                const float *jr = jrec + 12 * j;
-                const int4 ji = lds4i(jr);  // type, qadr, slo, shi
-                const int ty = ji.x, ad = ji.y;
-                V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
-                int i = ji.z;
-                for (; i + 4 <= ji.w; i += 4) {  // same left-to-right order; four wrenches in flight per LDS round trip
-                    V3 f4[4], t4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { f4[u] = ld3(sw + 6 * (i + u)); t4[u] = ld3(sw + 6 * (i + u) + 3); }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { Fs = add3(Fs, f4[u]); T0 = add3(T0, t4[u]); }
-                }
-                for (; i < ji.w; ++i) {
-                    Fs = add3(Fs, ld3(sw + 6 * i));
-                    T0 = add3(T0, ld3(sw + 6 * i + 3));
-                }
-                const V3 anchor = ld3(ja + 7 * j);
-                const Q4 prequat = ld4(ja + 7 * j + 3);
-                const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
-                if (ty == JHINGE) {
-                    const float4 ja4 = lds4(jr + 8);
-                    gg[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
-                } else if (ty == JSLIDE) {
-                    const float4 ja4 = lds4(jr + 8);
-                    gg[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), Fs);
-                } else {
-                    int qa = ad;
-                    V3 tl = tau;
-                    if (ty == JFREE) {
-                        st3(gg + ad, Fs);
-                        qa = ad + 3;
-                    } else {
-                        tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});
-                    }
-                    const Q4 qh = ld4(qsv + 4 * __builtin_bit_cast(int, lds4(jr + 4).w));  // saved by the pre-pass
-                    const V3 u = {qh.x, qh.y, qh.z};
-                    const V3 uxt = cross3(u, tl);
-                    const float n = jn[j];
-                    const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
-                    gg[qa] = (-2.0f * dot3(tl, u)) / dn;
-                    gg[qa + 1] = (2.0f * FMA(qh.w, tl.x, -uxt.x)) / dn;
-                    gg[qa + 2] = (2.0f * FMA(qh.w, tl.y, -uxt.y)) / dn;
-                    gg[qa + 3] = (2.0f * FMA(qh.w, tl.z, -uxt.z)) / dn;
-                }
-            }
+            for (int j = lg; j < H.naj; j += G) joint_gradient(j, CB);
             wave_sync();
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -421,7 +428,27 @@ void q_phase_kernel(const QArgs a) {
                 const int evaluated = (nls + cs >= a.maxls) ? cs : cs + 1;
                 const float pw = cs == 0 ? 1.0f : cs == 1 ? 0.5f : cs == 2 ? 0.25f : 0.125f;
                 const float eacc = eta * pw;
-                // (2) stopping residual from the gradient at the accepted candidate (group c*)
+                // (2) Only two of the eight evaluations need their gradient: the accepted candidate (group c*, for the
+                //     stopping residual) and the momentum point it leads to (group 4 + c*, the next iteration's grad f).
+                //     All 64 lanes share the 2 naj joints; every group then reads both vectors from LDS.
+                float *CBw = lds + plan_words + a.mb_words + (size_t)(wave * CPW) * H.chain_stride;
+                float *CBa = CBw + cs * H.chain_stride, *CBn = CBw + (4 + cs) * H.chain_stride;
+                for (int e = lane; e < nqpad; e += 64) { (CBa + H.c_gg)[e] = 0.0f; (CBn + H.c_gg)[e] = 0.0f; }
+                wave_sync();
+                for (int i = lane; i < 2 * H.naj; i += 64) {
+                    const bool nx = i >= H.naj;
+                    joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa);
+                }
+                wave_sync();
+                float gnext[NQR];
+#pragma unroll
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    const bool on = e < nq && ((mbits >> r) & 1u);
+                    gnew[r] = on ? (CBa + H.c_gg)[e] : 0.0f;
+                    gnext[r] = on ? (CBn + H.c_gg)[e] : 0.0f;
+                }
+                wave_sync();
                 float t0[NQR];
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
@@ -434,14 +461,10 @@ void q_phase_kernel(const QArgs a) {
                     }
                     t0[r] = a0;
                 }
-                const float e2_own = group_tree_sum<G, NQR>(t0);
-                const float e2 = __shfl(e2_own, cs * 8, 64);
+                const float e2 = group_tree_sum<G, NQR>(t0);  // the same value in every group
                 const float fx_c = __shfl(loss, cs * 8, 64);
-                // (3) f, grad f at the next momentum point come from group 4 + c*
+                // (3) f at the next momentum point comes from group 4 + c*
                 const float fy_next = __shfl(loss, (4 + cs) * 8, 64);
-                float gnext[NQR];
-#pragma unroll
-                for (int r = 0; r < NQR; ++r) gnext[r] = __shfl(gnew[r], (4 + cs) * 8 + lg, 64);
                 if (st_in == ST_SPEC) {
                     c_ls += evaluated;
                     c_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
