@@ -514,19 +514,25 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
     return fk_impl(m, qpos, N, qn, xpos, xquat, site_xpos, 1, stream);
 }
 
-// Lanes per chain.  Fewer lanes = more chains per wave instruction (throughput); more lanes = fewer
-// idle chains when there are few of them (latency).  Take the smallest G in {16, 32, 64} for which the
-// chains fill at least half of that G's resident slots (8 and 4 lanes only on request: with the current
-// LDS footprint they cannot keep two waves per SIMD resident).
-static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds) {
+// Lanes per chain.  Fewer lanes = more chains per wave instruction (throughput); more lanes = fewer idle lanes
+// when there are few chains (latency).  Measured on the rodent (20-frame clips, frames/s in thousands):
+//   chains      500   1000   1500   2000   3000   5000   8000
+//   latency     63    123    168    125    170    158      -      (speculative kernel, 1536 chains resident)
+//   G = 64      34     68     90    120    126    150      -
+//   G = 32      31     59     86    115    155    216      -
+//   G = 16      25     51     72     96    140    212    334
+// i.e. the latency mode up to about 2.3 x its resident capacity, then 32 lanes until the 16-lane kernel has
+// about 45 % of its slots filled (8 and 4 lanes only on request: with the LDS footprint of a chain they cannot
+// keep two waves per SIMD resident).  Returns 0 for the latency mode.
+static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
-    const int cand[] = {16, 32, 64};
-    for (int G : cand) {
-        const QShape sh = pick_shape(m->h, G, nkinds);
-        if (!sh.wpb) continue;
-        const long capacity = (long)sh.waves_per_cu * kCus * (64 / G);
-        if (nchains > capacity / 2) return G;
+    if (spec_allowed) {
+        const QShape ss = pick_shape(m->h, 8, nkinds);  // one chain per wave, eight 8-lane evaluation groups
+        if (ss.wpb && (long)nchains * 10 <= (long)ss.waves_per_cu * kCus * 23) return 0;
     }
+    const QShape s16 = pick_shape(m->h, 16, nkinds);
+    if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 45) return 16;
+    if (nchains > 2500 && pick_shape(m->h, 32, nkinds).wpb) return 32;
     return 64;
 }
 
@@ -546,14 +552,15 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), s);
     a.prof = d_prof;
 #endif
-    int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds);
+    int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds, !a.single);
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
     // Latency mode: when there are so few chains that each would get a whole wavefront anyway (G = 64), let
     // the wavefront's eight 8-lane groups evaluate the line-search candidates and next momentum points of
     // that ONE chain speculatively (q_phase_kernel<8, ., ., true>): one trip per iteration instead of three.
-    int spec = (!a.single && p->lanes_per_chain == 0 && G == 64) ? 1 : 0;
+    int spec = G == 0 ? 1 : 0;
     if (const char *w = getenv("STAC_HIP_SPEC")) spec = a.single ? 0 : atoi(w);
+    if (G == 0) G = spec ? 64 : 32;
     if (spec) {
         QShape sh = pick_shape(m->h, 8, nkinds, nchains);  // 8 groups of 8 lanes: same LDS as eight 8-lane chains
         if (sh.wpb) {
