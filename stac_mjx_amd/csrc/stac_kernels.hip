@@ -11,12 +11,14 @@
 //                    outputs of pose_optimization (compute_stac.py:261-264).
 //   m_* kernels      the cross-frame sums and closed form of _m_opt (stac_core.py:102-172).
 //
-// Execution model: a workgroup holds 1-8 independent 64-lane wavefronts that only share one LDS copy of
-// the model plan.  A wavefront is split into 64/G groups of G lanes; each group owns one chain (clip) and cooperates on it: lanes of a group take the bodies
-// of one tree level, the marker sites, the joints, and 1/G of every nq-vector (held in registers).
-// The model "plan" (active subtree tables) and the per-chain transforms live in LDS.  Every group
-// runs its own solver state machine, so chains of one wavefront may be in different solves, line
-// searches or frames: each trip round the main loop is one q_loss evaluation for every group.
+// Execution model: a workgroup holds 1-10 independent 64-lane wavefronts that only share one LDS copy of
+// the model plan.  A wavefront is split into 64/G groups of G lanes; each group owns one chain (clip) and
+// cooperates on it: lanes of a group take the joints (joint-local pre-pass, gradient pass), the marker
+// sites, 1/G of every nq-vector (held in registers) and -- max_width of them -- the bodies of the tree
+// levels (FK program / level loop, stac_device.hpp).  The model "plan" (active subtree tables, FK step
+// records) and the per-chain arrays live in LDS.  Every group runs its own solver state machine, so chains
+// of one wavefront may be in different solves, line searches or frames: each trip round the main loop is
+// one q_loss evaluation for every group.
 //
 // Arithmetic contract: every float operation sequence here is the one of oracle/stac_oracle.c
 // (same expression trees with the same explicit fma placement, same summation orders; build with
@@ -33,8 +35,8 @@ namespace stac {
 // q_phase kernel
 // ------------------------------------------------------------------------------------------------
 
-// WPE = waves per SIMD the register allocation is capped for (2 -> 256 VGPRs, 4 -> 128 VGPRs): the host
-// picks the variant that lets all chains of a launch be resident at once.
+// WPE = waves per SIMD the register allocation is capped for (2 -> 256 VGPRs, 3 -> 168 VGPRs in workgroups of
+// up to ten waves, 4 -> 128 VGPRs): the host picks the variant that lets the most chains be resident.
 //
 // SPEC (latency mode, G == 8 only): the eight lane groups of a wavefront all work on ONE chain.  After a
 // bootstrap evaluation of f, grad f at y, every trip evaluates in parallel the four line-search candidates
@@ -42,6 +44,7 @@ namespace stac {
 // y_next(c) they would lead to (groups 4-7).  The first acceptable candidate c* is taken exactly as the
 // sequential algorithm would; its gradient gives the stopping residual and group 4+c* already holds
 // f, grad f at the next y: one trip per PG iteration instead of three, identical arithmetic per evaluation.
+// The joint pass of such a trip runs after the choice, for those two evaluations only, on all 64 lanes.
 template <int G, int NQR, int WPE, bool SPEC>
 __global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
