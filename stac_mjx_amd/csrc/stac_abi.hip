@@ -58,6 +58,11 @@ struct stac_model {
     std::vector<uint8_t> masks_cache;  // what d_masks currently holds (uploads + their sync happen only on change)
     // host copies of the plan's structure, used to build the LM solver's per-kind tables
     std::vector<int> h_ab_parent, h_aj_type, h_aj_qadr, h_aj_slot, h_aj_slo, h_aj_shi, h_sortpos;
+    // what build_fk_program needs (the root passes get a pruned program per call)
+    std::vector<BodyRec> h_brec;
+    std::vector<int> h_lev_adr, h_ab_jadr, h_ab_jnum, h_xf, h_site_slot;
+    std::vector<float> h_aj_pos;
+    int n_mlev_root = 0;        // micro-levels of the root-pass program currently in the blob (0 = none)
     int32_t *d_lm_tab = nullptr;
     size_t lm_tab_words = 0;
     std::vector<int32_t> lm_tab_cache;
@@ -103,6 +108,61 @@ extern "C" int32_t stac_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// The FK program of the bodies in `need` (null: all active bodies): FkStep records at (micro_level * max_width +
+// position in the level).  Positions are those of the full layout, so a child still follows its parent on one lane.
+static std::vector<int32_t> build_fk_program(const stac_model *m, const char *need, int *n_mlev_out) {
+    const PlanHeader &h = m->h;
+    const int W = h.max_width, rw = h.fk_rec_words, nlev = h.nlev;
+    const std::vector<int> &lev_adr = m->h_lev_adr;
+    std::vector<int> mfirst(nlev + 1, 0);
+    for (int l = 0; l < nlev; ++l) {
+        int mm = 0;
+        for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s)
+            if (!need || need[s]) mm = std::max(mm, std::max(1, m->h_ab_jnum[s]));
+        mfirst[l + 1] = mfirst[l] + mm;
+    }
+    const int n_mlev = std::max((mfirst[nlev] + 1) & ~1, 2);  // even: the kernel runs two steps per loop trip
+    std::vector<int32_t> prog((size_t)n_mlev * W * rw, 0);
+    auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    for (int l = 0; l < nlev; ++l)
+        for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) {
+            if (need && !need[s]) continue;
+            const BodyRec &br = m->h_brec[s];
+            const int pp = s - lev_adr[l], njs = m->h_ab_jnum[s], nsteps = std::max(1, njs), xfs = m->h_xf[s];
+            for (int i = 0; i < nsteps; ++i) {
+                int32_t *r = prog.data() + ((size_t)(mfirst[l] + i) * W + pp) * rw;
+                int32_t fl = 0;
+                if (i == 0) {
+                    fl |= FK_BODY;
+                    if (!(br.flags & 2)) fl |= FK_PARENT_LDS;
+                    if (!(br.flags & 1)) fl |= FK_BQUAT;
+                    r[1] = br.parent;
+                    for (int c = 0; c < 3; ++c) r[4 + c] = f2i(br.pos[c]);
+                    if (rw == 16) for (int c = 0; c < 4; ++c) r[12 + c] = f2i(br.quat[c]);
+                }
+                if (i < njs) {
+                    const int j = m->h_ab_jadr[s] + i;
+                    const float *jp = m->h_aj_pos.data() + 3 * j;
+                    fl |= FK_JOINT | (m->h_aj_type[j] << FK_JTYPE_SHIFT);
+                    if (jp[0] == 0.0f && jp[1] == 0.0f && jp[2] == 0.0f) fl |= FK_JZERO;
+                    r[2] = j;
+                    for (int c = 0; c < 3; ++c) r[8 + c] = f2i(jp[c]);
+                    r[11] = m->h_aj_qadr[j];
+                }
+                if (i == nsteps - 1 && xfs >= 0) fl |= FK_LAST;
+                r[0] = fl;
+                r[7] = std::max(xfs, 0);
+            }
+        }
+    for (int ml = 0; ml + 1 < n_mlev; ++ml)
+        for (int pp = 0; pp < W; ++pp) {
+            const int32_t *nx = prog.data() + ((size_t)(ml + 1) * W + pp) * rw;
+            if (nx[0] & FK_JOINT) prog[((size_t)ml * W + pp) * rw + 3] = nx[2];
+        }
+    *n_mlev_out = n_mlev;
+    return prog;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,6 +278,8 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     for (int l = 0; l < nlev; ++l) h.max_width = std::max(h.max_width, lev_adr[l + 1] - lev_adr[l]);
     m->h_ab_parent = ab_parent; m->h_aj_type = aj_type; m->h_aj_qadr = aj_qadr; m->h_aj_slot = aj_slot;
     m->h_aj_slo = aj_slo; m->h_aj_shi = aj_shi; m->h_sortpos = sortpos;
+    m->h_site_slot.resize(K);
+    for (int k = 0; k < K; ++k) m->h_site_slot[k] = slot_of[t->site_bodyid[k]];
     if (nab >= 65535 || K >= 65535) return fail(STAC_ERR_CAPACITY, "too many bodies / sites");
     if (K > 4096) return fail(STAC_ERR_CAPACITY, "more than 4096 fit sites");
 
@@ -298,55 +360,20 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     quat_adr.push_back(0);
     h.off_quat_adr = put_raw(quat_adr.data(), quat_adr.size());
     h.core_words = (int)B.size();  // what a kernel that walks the levels itself stages in LDS
-    {   // FK program (FkStep records, see stac_plan.hpp)
-        const int W = h.max_width;
+    {   // FK program (FkStep records, see stac_plan.hpp); a second area of the same size takes the pruned program of
+        // the root passes, which depends on the call's trunk keypoints (fill_root_program)
+        m->h_brec = brec; m->h_lev_adr = lev_adr; m->h_ab_jadr = ab_jadr; m->h_ab_jnum = ab_jnum; m->h_xf = xf;
+        m->h_aj_pos = aj_pos;
         bool any_bquat = false;
         for (int s = 0; s < nab; ++s) any_bquat = any_bquat || !(brec[s].flags & 1);
-        const int rw = any_bquat ? 16 : 12;
-        std::vector<int> mfirst(nlev + 1, 0);
-        for (int l = 0; l < nlev; ++l) {
-            int mm = 1;
-            for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) mm = std::max(mm, ab_jnum[s]);
-            mfirst[l + 1] = mfirst[l] + mm;
-        }
-        const int n_mlev = (mfirst[nlev] + 1) & ~1;  // even: the kernel runs two steps per loop trip (an empty level pads)
-        std::vector<int32_t> prog((size_t)n_mlev * W * rw, 0);
-        auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
-        for (int l = 0; l < nlev; ++l)
-            for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) {
-                const int pp = s - lev_adr[l], njs = ab_jnum[s], nsteps = std::max(1, njs);
-                for (int i = 0; i < nsteps; ++i) {
-                    int32_t *r = prog.data() + ((size_t)(mfirst[l] + i) * W + pp) * rw;
-                    int32_t fl = 0;
-                    if (i == 0) {
-                        fl |= FK_BODY;
-                        if (!(brec[s].flags & 2)) fl |= FK_PARENT_LDS;
-                        if (!(brec[s].flags & 1)) fl |= FK_BQUAT;
-                        r[1] = brec[s].parent;
-                        for (int c = 0; c < 3; ++c) r[4 + c] = f2i(brec[s].pos[c]);
-                        if (rw == 16) for (int c = 0; c < 4; ++c) r[12 + c] = f2i(brec[s].quat[c]);
-                    }
-                    if (i < njs) {
-                        const int j = ab_jadr[s] + i;
-                        fl |= FK_JOINT | (aj_type[j] << FK_JTYPE_SHIFT);
-                        if (aj_pos[3 * j] == 0.0f && aj_pos[3 * j + 1] == 0.0f && aj_pos[3 * j + 2] == 0.0f) fl |= FK_JZERO;
-                        r[2] = j;
-                        for (int c = 0; c < 3; ++c) r[8 + c] = f2i(aj_pos[3 * j + c]);
-                        r[11] = aj_qadr[j];
-                    }
-                    if (i == nsteps - 1 && xf[s] >= 0) fl |= FK_LAST;
-                    r[0] = fl;
-                    r[7] = std::max(xf[s], 0);
-                }
-            }
-        for (int ml = 0; ml + 1 < n_mlev; ++ml)
-            for (int pp = 0; pp < W; ++pp) {
-                const int32_t *nx = prog.data() + ((size_t)(ml + 1) * W + pp) * rw;
-                if (nx[0] & FK_JOINT) prog[((size_t)ml * W + pp) * rw + 3] = nx[2];
-            }
+        h.fk_rec_words = any_bquat ? 16 : 12;
+        int n_mlev = 0;
+        const std::vector<int32_t> prog = build_fk_program(m, nullptr, &n_mlev);
         h.off_fkstep = put_raw(prog.data(), prog.size());
         h.n_mlev = n_mlev;
-        h.fk_rec_words = rw;
+        std::vector<int32_t> blank(prog.size(), 0);
+        h.off_fkroot = put_raw(blank.data(), blank.size());
+        m->n_mlev_root = 0;
     }
     h.total_words = (int)B.size();
 
@@ -811,6 +838,28 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     return STAC_OK;
 }
 
+// Root passes weigh the trunk keypoints only: every other site contributes exact zeros there, so the kinematics of
+// the bodies that carry no trunk keypoint are not needed.  Builds the FK program of the needed bodies into the
+// blob's second program area; the kernel runs it when every chain of a wavefront is in a root pass.
+static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enable, hipStream_t s) {
+    const PlanHeader &h = m->h;
+    m->n_mlev_root = 0;
+    if (!enable || getenv("STAC_HIP_NOPRUNE")) return STAC_OK;
+    std::vector<char> need(h.nab, 0);
+    int n_need = 0;
+    for (int k = 0; k < h.K; ++k)
+        if (trunk_kps[k])
+            for (int sl = m->h_site_slot[k]; sl >= 0 && !need[sl]; sl = m->h_ab_parent[sl] - 1) { need[sl] = 1; ++n_need; }
+    if (n_need == 0 || n_need == h.nab) return STAC_OK;  // nothing to prune (or nothing weighted at all)
+    int n_mlev = 0;
+    const std::vector<int32_t> prog = build_fk_program(m, need.data(), &n_mlev);
+    int32_t *dst = reinterpret_cast<int32_t *>(m->blob_host.data()) + h.off_fkroot;
+    std::memcpy(dst, prog.data(), prog.size() * 4);
+    HIP_TRY(hipMemcpyAsync(m->d_blob + h.off_fkroot, dst, prog.size() * 4, hipMemcpyHostToDevice, s));
+    m->n_mlev_root = n_mlev;
+    return STAC_OK;
+}
+
 extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, const float *kp, const float *q0,
                                 const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, int32_t N,
                                 float *params_out, float *state_out, uint32_t *counters_out, void *stream) {
@@ -869,12 +918,16 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     if (hostm != m->masks_cache) {
         HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), (size_t)(P + 3) * nqpad, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_kpw, hostm.data() + (size_t)(P + 3) * nqpad, 2 * K, hipMemcpyHostToDevice, s));
+        m->masks_cache.clear();
+        const int rc = fill_root_program(m, hostm.data() + (size_t)(P + 3) * nqpad, do_root_opt != 0, s);
+        if (rc != STAC_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
         m->masks_cache = hostm;
     }
     QArgs a{};
     a.kp = kp; a.q_init = q_init; a.masks = m->d_masks; a.kpw = d_kpw; a.kpw3 = nullptr;
     a.C = C; a.F = F; a.P = P; a.root_kp_idx = root_kp_idx; a.do_root_opt = do_root_opt ? 1 : 0; a.single = 0;
+    a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;
     a.kpw_sorted = d_kpw + K;
     const int rc = p->solver == STAC_SOLVER_LM ? run_q_lm(m, p, a, C, hostm.data(), s) : run_q(m, p, a, C, s);

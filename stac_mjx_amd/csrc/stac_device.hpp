@@ -332,10 +332,10 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
 }
 template <int RW>
 __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
-                                           const bool active, const bool store_ja) {
+                                           const bool active, const bool store_ja, const int prog_off, const int n_ml) {
     const int W = H.max_width;
     const bool on = active && lf < W;
-    const float *sp = P + H.off_fkstep + RW * (on ? lf : 0);
+    const float *sp = P + prog_off + RW * (on ? lf : 0);
     const float *jrec = P + H.off_joint;
     float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
     const float *qe = CBc + H.c_qe;
@@ -347,20 +347,24 @@ __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, 
     A.ql = ld4(ja + 3 + 7 * A.r0.z);
     const int stride = RW * W;
     // two steps per trip so that the fetched record never has to be copied (n_mlev is even: padded by the host)
-    for (int ml = 0; ml < H.n_mlev; ml += 2) {
+    for (int ml = 0; ml < n_ml; ml += 2) {
         sp += stride;
         fk_step<RW>(A, B, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
-        if (ml + 2 < H.n_mlev) sp += stride;
+        if (ml + 2 < n_ml) sp += stride;
         fk_step<RW>(B, A, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
     }
 }
 
 // FK of one chain by gf lanes: the program when every level fits the lanes, else the level loop.
+// n_ml_root > 0 (wave-uniform): every chain of the wavefront is in a root pass -- run the pruned program at off_fkroot.
 __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
-                                         const bool active, const bool store_ja, const bool use_levels) {
+                                         const bool active, const bool store_ja, const bool use_levels,
+                                         const int n_ml_root = 0) {
     if (H.max_width <= gf && !use_levels) {
-        if (H.fk_rec_words == 16) fk_program<16>(H, P, CBc, lf, gf, active, store_ja);
-        else fk_program<12>(H, P, CBc, lf, gf, active, store_ja);
+        const int prog_off = n_ml_root > 0 ? H.off_fkroot : H.off_fkstep;
+        const int n_ml = n_ml_root > 0 ? n_ml_root : H.n_mlev;
+        if (H.fk_rec_words == 16) fk_program<16>(H, P, CBc, lf, gf, active, store_ja, prog_off, n_ml);
+        else fk_program<12>(H, P, CBc, lf, gf, active, store_ja, prog_off, n_ml);
     } else {
         fk_levels(H, P, CBc, lf, gf, active, store_ja);
     }

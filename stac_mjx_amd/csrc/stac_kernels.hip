@@ -168,7 +168,11 @@ void q_phase_kernel(const QArgs a) {
         PROF_TICK(10);  // joint-local pre-pass
 
         // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
-        fk_chain(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0);
+        // root passes weigh the trunk keypoints only: when every chain of the wave is in one, the kinematics stop at
+        // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)
+        const bool root_pass = !a.single && kind < 2;
+        const int n_ml_root = (a.n_mlev_root > 0 && !__any(st_in != ST_DONE && !root_pass)) ? a.n_mlev_root : 0;
+        fk_chain(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root);
 
         PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
@@ -187,11 +191,15 @@ void q_phase_kernel(const QArgs a) {
             } else {
                 w0 = w1 = w2 = (trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f);
             }
-            const float rx = (kpl[3 * k] - sx.x) * w0, ry = (kpl[3 * k + 1] - sx.y) * w1, rz = (kpl[3 * k + 2] - sx.z) * w2;
+            // a site without weight: exact zeros, written without looking at its body (which a pruned FK has skipped)
+            const bool wz = (w0 == 0.0f) && (w1 == 0.0f) && (w2 == 0.0f);
+            const float rx = wz ? 0.0f : (kpl[3 * k] - sx.x) * w0, ry = wz ? 0.0f : (kpl[3 * k + 1] - sx.y) * w1,
+                        rz = wz ? 0.0f : (kpl[3 * k + 2] - sx.z) * w2;
             const float term = FMA(rz, rz, FMA(ry, ry, rx * rx));
             if (any_grad) {
                 const V3 f = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
-                const V3 tq = cross3(sub3(sx, cref), f);
+                V3 tq = cross3(sub3(sx, cref), f);
+                if (wz) tq = V3{0.0f, 0.0f, 0.0f};
                 const int sp = ss >> 16;
                 st3(sw + 6 * sp, f);
                 st3(sw + 6 * sp + 3, tq);

@@ -98,6 +98,7 @@ struct PlanHeader {
     int32_t kpow2;     // K rounded up to a power of two (the LDS loss tree of models with more than 64 sites)
     int32_t c_qsv;     // [4*nqj] their normalised quaternions, kept for the gradient pass
     int32_t off_fkstep;    // FkStep[n_mlev * max_width] (word offset into the blob)
+    int32_t off_fkroot;    // same size: the pruned program of the root passes (filled per call from the trunk keypoints)
     int32_t n_mlev;        // micro-levels of the FK program
     int32_t fk_rec_words;  // 12, or 16 when the records carry body_quat
 };
@@ -128,6 +129,7 @@ struct QArgs {
     int32_t root_kp_idx, do_root_opt;
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
     int32_t mb_words;       // LDS words reserved for the per-kind mask bit table (multiple of 4)
+    int32_t n_mlev_root;    // micro-levels of the root-pass FK program at h.off_fkroot; 0 = none (never prune)
     int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program (A/B switches)
     float tol;
     int32_t maxiter, maxls;
