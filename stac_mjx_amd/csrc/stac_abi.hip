@@ -928,6 +928,16 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.kp = kp; a.q_init = q_init; a.masks = m->d_masks; a.kpw = d_kpw; a.kpw3 = nullptr;
     a.C = C; a.F = F; a.P = P; a.root_kp_idx = root_kp_idx; a.do_root_opt = do_root_opt ? 1 : 0; a.single = 0;
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
+    // joints whose coordinates the root passes optimise: a prefix of the active joints (the root body comes first);
+    // the gradient pass of a pruned root-pass trip stops there (the other gradients are masked out anyway)
+    a.n_root_joints = m->h.naj;
+    if (do_root_opt) {
+        int nrj = 0;
+        while (nrj < m->h.naj && m->h_aj_qadr[nrj] < root_dims) ++nrj;
+        bool prefix = true;
+        for (int j = nrj; j < m->h.naj; ++j) prefix = prefix && m->h_aj_qadr[j] >= root_dims;
+        if (prefix) a.n_root_joints = nrj;
+    }
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;
     a.kpw_sorted = d_kpw + K;
     const int rc = p->solver == STAC_SOLVER_LM ? run_q_lm(m, p, a, C, hostm.data(), s) : run_q(m, p, a, C, s);

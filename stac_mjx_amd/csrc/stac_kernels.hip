@@ -313,7 +313,8 @@ void q_phase_kernel(const QArgs a) {
             PROF_TICK(5);  // zero gg
             // ---- per-joint gradient: subtree wrench of the joint's body = its sites in
             //      (body id, site id) order, summed from zero, then the joint formulas ---------------------
-            for (int j = lg; j < H.naj; j += G) joint_gradient(j, CB);
+            const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
+            for (int j = lg; j < naj_g; j += G) joint_gradient(j, CB);
             wave_sync();
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {

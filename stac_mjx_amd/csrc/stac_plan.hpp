@@ -130,6 +130,7 @@ struct QArgs {
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
     int32_t mb_words;       // LDS words reserved for the per-kind mask bit table (multiple of 4)
     int32_t n_mlev_root;    // micro-levels of the root-pass FK program at h.off_fkroot; 0 = none (never prune)
+    int32_t n_root_joints;  // leading active joints that carry the root passes' coordinates
     int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program (A/B switches)
     float tol;
     int32_t maxiter, maxls;
