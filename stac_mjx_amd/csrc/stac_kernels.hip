@@ -134,9 +134,13 @@ void q_phase_kernel(const QArgs a) {
         // needs (the oracle's separate VG_X evaluation runs the very same FK).  The step size doubles
         // after every iteration, so the first candidate is almost always rejected and the second
         // accepted: evaluate the gradient together with every candidate after the first.
-        const bool ls_with_grad = (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
-        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_with_grad || (SPEC && st_in == ST_SPEC);
+        const bool ls_wants_grad = (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
+        const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_wants_grad || (SPEC && st_in == ST_SPEC);
         const bool any_grad = __any(want_grad);
+        // The gradient pass is issued for the whole wavefront as soon as one group needs it, so a FIRST candidate gets
+        // its gradient for free whenever a neighbour chain asks for one -- and if it is accepted (one iteration in six)
+        // the separate evaluation of x_next disappears as well.
+        const bool ls_with_grad = (st_in == ST_LS) && !(a.flags & 1) && (nls >= 1 || any_grad);
         // t_next and the momentum coefficient of the running iteration (functions of t only; recomputed every
         // trip instead of being carried); SPEC: this group's candidate scale 2^-c
         const float spec_pow = SPEC ? ((role & 3) == 0 ? 1.0f : (role & 3) == 1 ? 0.5f : (role & 3) == 2 ? 0.25f : 0.125f) : 1.0f;
