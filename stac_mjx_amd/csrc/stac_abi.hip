@@ -68,6 +68,10 @@ struct stac_model {
     std::vector<int32_t> lm_tab_cache;
     LmArgs lm_args{};
     size_t masks_bytes = 0;
+    int32_t *d_ctl = nullptr;    // straggler hand-off: {finished, threshold, handed off, capacity}
+    float *d_hand = nullptr;     // [hand_cap][3 nqpad + 12] solver states in transit
+    int hand_cap = 0;
+    int32_t h_ctl[4] = {0, 0, 0, 0};
     float *d_scratch = nullptr;  // grown on demand (xpos/xquat when the caller does not want them)
     size_t scratch_floats = 0;
     int max_depth = 0;
@@ -487,7 +491,7 @@ extern "C" void stac_model_destroy(stac_model *m) {
     if (!m) return;
     void *ptrs[] = {m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
                     m->d_body_quat, m->d_jnt_type, m->d_jnt_qposadr, m->d_jnt_pos, m->d_jnt_axis,
-                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab};
+                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab, m->d_ctl, m->d_hand};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -624,7 +628,47 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
                     nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), m->h.chain_stride, a.h.total_words);
         a.mb_words = q_mb_words(nkinds, G);
+        // Straggler hand-off: chains take very different numbers of iterations (the slowest of 10 000 about 1.6x the
+        // mean), so the launch would end on a few waves per CU.  Once all but `hcap` chains are done, the rest move to
+        // the latency kernel at their next iteration boundary (QArgs::ctl).
+        int hcap = 0;
+        if (!a.single && !(a.flags & 3) && m->h.max_width <= 8) {
+            const QShape ss = pick_shape(m->h, 8, nkinds);
+            const int spec_cap = ss.wpb ? ss.waves_per_cu * kCus : 0;
+            // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
+            if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
+            if (const char *w = getenv("STAC_HIP_HANDOFF")) hcap = spec_cap ? std::min(std::max(atoi(w), 0), nchains) : 0;
+        }
+        if (hcap > 0) {
+            const size_t hstride = 3 * (size_t)m->h.nqpad + 12;
+            if (hcap > m->hand_cap) {
+                if (m->d_hand) (void)hipFree(m->d_hand);
+                m->d_hand = nullptr; m->hand_cap = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)hcap * hstride * sizeof(float)));
+                m->hand_cap = hcap;
+            }
+            if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 4 * sizeof(int32_t)));
+            m->h_ctl[0] = 0; m->h_ctl[1] = nchains - hcap; m->h_ctl[2] = 0; m->h_ctl[3] = hcap;
+            HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
+            a.ctl = m->d_ctl; a.hand = m->d_hand;
+        }
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
+        if (cap && e == hipSuccess && hcap > 0) {
+            // second launch: the latency kernel resumes whatever was handed off (waves without an entry exit at once)
+            QArgs b = a;
+            b.resume = 1; b.resume_slots = hcap;
+            b.h = m->h;
+            b.flags = a.flags & ~2;
+            QShape ss = pick_shape(m->h, 8, nkinds, hcap);
+            ss.wpe = 2;
+            while (ss.wpb > 1 && q_lds_bytes(m->h, 8, nkinds, ss.wpb) > kLdsPerCu) --ss.wpb;
+            b.mb_words = q_mb_words(nkinds, 8);
+            int cap2 = 0;
+            e = launch_q_phase(b, 8, ss.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, ss.wpb), s, &cap2);
+            if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
+            if (getenv("STAC_HIP_VERBOSE")) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.wpb);
+        }
+        a.ctl = nullptr; a.hand = nullptr;
         if (cap) break;  // an instantiation with this many lanes holds nq
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");

@@ -84,7 +84,13 @@ void q_phase_kernel(const QArgs a) {
     const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
     // ---- per-chain solver state (uniform inside a group) ------------------------------------------
-    const int chain = SPEC ? (blockIdx.x * wpb + wave) : (blockIdx.x * wpb + wave) * CPW + grp;
+    const int slot_id = SPEC ? (blockIdx.x * wpb + wave) : (blockIdx.x * wpb + wave) * CPW + grp;
+    const int hstride = 3 * nqpad + 12;
+    // resume = 1: this launch continues the chains that the throughput kernel handed off (QArgs::ctl / hand)
+    const bool resuming = a.resume != 0 && slot_id < a.ctl[2] && slot_id < a.ctl[3];
+    const float *hs = a.hand + (size_t)(resuming ? slot_id : 0) * hstride;
+    const int *hi = reinterpret_cast<const int *>(hs + 3 * nqpad);
+    const int chain = a.resume ? (resuming ? hi[0] : a.C) : slot_id;
     const int role = grp;  // SPEC: 0-3 candidate c, 4-7 momentum point of candidate c
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
@@ -92,6 +98,12 @@ void q_phase_kernel(const QArgs a) {
     float stepsize = 1.0f, t = 1.0f, eta = 1.0f, fy = 0.0f, fx = 0.0f;
     float error = __builtin_inff();
     uint32_t c_iter = 0, c_ls = 0, c_grad = 0, c_solves = 0;
+    if (resuming) {
+        kind = hi[1]; frame = hi[2]; iter = hi[3];
+        stepsize = hs[3 * nqpad + 4]; t = hs[3 * nqpad + 5];
+        c_iter = (uint32_t)hi[6]; c_ls = (uint32_t)hi[7]; c_grad = (uint32_t)hi[8]; c_solves = (uint32_t)hi[9];
+        fx = hs[3 * nqpad + 10]; error = hs[3 * nqpad + 11];
+    }
 
     float x[NQR], y[NQR], g[NQR], q0[NQR];
     // the line-search candidate clip(y - eta * g) is recomputed where it is needed (same bits, fewer registers)
@@ -111,8 +123,8 @@ void q_phase_kernel(const QArgs a) {
         q0[r] = v;
     }
     if (st != ST_DONE) {
-        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + i];
-        if (!a.single && kind < 2) {  // root pass: q0[:3] = keypoint of the root marker (compute_stac.py:57-59)
+        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
+        if (!a.single && kind < 2 && !resuming) {  // root pass: q0[:3] = keypoint of the root marker (compute_stac.py:57-59)
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
@@ -122,12 +134,51 @@ void q_phase_kernel(const QArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; }
+    if (resuming) {
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            if (e < nq) { x[r] = hs[e]; y[r] = hs[nqpad + e]; q0[r] = hs[2 * nqpad + e]; }
+        }
+    }
     wave_sync();
 
     PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
     while (__any(st != ST_DONE)) {
         PROF_TICK(0);  // loop control
+        if (!SPEC && a.ctl && !a.resume) {
+            // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
+            // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
+            // (looked at every fourth iteration: the counter lives in L2)
+            if (__any(st == ST_VG_Y && (iter & 3) == 0)) {
+                const int done_cnt = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (st == ST_VG_Y && (iter & 3) == 0 && done_cnt >= a.ctl[1]) {
+                    int slot = 0;
+                    if (lg == 0) slot = atomicAdd(a.ctl + 2, 1);
+                    slot = __shfl(slot, grp * G, 64);
+                    if (slot < a.ctl[3]) {
+                        float *hd = a.hand + (size_t)slot * hstride;
+#pragma unroll
+                        for (int r = 0; r < NQR; ++r) {
+                            const int e = r * G + lg;
+                            if (e < nq) { hd[e] = x[r]; hd[nqpad + e] = y[r]; hd[2 * nqpad + e] = q0[r]; }
+                        }
+                        if (lg == 0) {
+                            int *hdi = reinterpret_cast<int *>(hd + 3 * nqpad);
+                            hdi[0] = chain; hdi[1] = kind; hdi[2] = frame; hdi[3] = iter;
+                            hd[3 * nqpad + 4] = stepsize; hd[3 * nqpad + 5] = t;
+                            hdi[6] = (int)c_iter; hdi[7] = (int)c_ls; hdi[8] = (int)c_grad; hdi[9] = (int)c_solves;
+                            hd[3 * nqpad + 10] = fx; hd[3 * nqpad + 11] = error;
+                        }
+                        st = ST_DONE;
+                    } else if (lg == 0) {
+                        atomicAdd(a.ctl + 2, -1);  // no room: stay
+                    }
+                }
+            }
+            if (!__any(st != ST_DONE)) break;
+        }
         const int st_in = st;
         const uint32_t mbits = MB[kind * G + lg];
         // A line-search candidate that is accepted becomes x_next, whose gradient the stopping test
@@ -575,6 +626,7 @@ void q_phase_kernel(const QArgs a) {
                             if (a.q_carry_out && (!SPEC || role == 0))
                                 for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
                             st = ST_DONE;
+                            if (!SPEC && a.ctl && lg == 0) atomicAdd(a.ctl, 1);  // finished chains (hand-off threshold)
                         } else {
                             for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
                         }
@@ -733,7 +785,8 @@ template <int G, int NQR, int WPE, bool SPEC>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = SPEC ? 1 : 64 / G;
     const int per_block = CPW * wpb;
-    const int blocks = (a.C + per_block - 1) / per_block;
+    const int slots = a.resume ? a.resume_slots : a.C;  // a resume launch has one slot per hand-off entry
+    const int blocks = (slots + per_block - 1) / per_block;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;

@@ -131,6 +131,15 @@ struct QArgs {
     int32_t mb_words;       // LDS words reserved for the per-kind mask bit table (multiple of 4)
     int32_t n_mlev_root;    // micro-levels of the root-pass FK program at h.off_fkroot; 0 = none (never prune)
     int32_t n_root_joints;  // leading active joints that carry the root passes' coordinates
+    // Straggler hand-off (null = off).  Chains take very different numbers of iterations; once most of a launch's
+    // chains are done the rest would drag on at a few waves per CU.  ctl = {finished chains, threshold, handed-off
+    // chains, capacity}: a chain of the throughput kernel that starts an iteration (state VG_Y) after `finished`
+    // has reached `threshold` writes its solver state to hand[] and stops; a second launch of the latency kernel
+    // (resume = 1, one chain per wavefront) picks the states up and finishes them, one trip per iteration.
+    int32_t *ctl;
+    float *hand;            // [capacity][3 * nqpad + 12]: x, y, q0, then {chain, kind, frame, iter, stepsize, t, c_iter, c_ls, c_grad, c_solves, fx, error}
+    int32_t resume;
+    int32_t resume_slots;   // grid size of the resume launch (= capacity)
     int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program (A/B switches)
     float tol;
     int32_t maxiter, maxls;

@@ -173,6 +173,23 @@ def test_q_phase_register_cap_variants(rodent_setup, rodent_mocap, monkeypatch, 
     _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims))
 
 
+@pytest.mark.parametrize("frames", [1, 3])
+@pytest.mark.parametrize("handoff", ["12", "40"])
+def test_q_phase_straggler_handoff(rodent_setup, rodent_mocap, monkeypatch, frames, handoff):
+    """Once most chains of a launch are done, the rest move from the throughput kernel to the latency kernel at an
+    iteration boundary (solver state through global memory).  Forced here on a small batch: results, residuals and
+    counters still equal the oracle bit for bit, whichever kernel finished a chain."""
+    monkeypatch.setenv("STAC_HIP_HANDOFF", handoff)
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=16, maxiter=60), _oracle(fs, maxiter=60)
+    kp = rodent_mocap[500:500 + 44 * frames].reshape(44, frames, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(res, ref)
+    np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
+
+
 def test_q_phase_carried_chain_no_root_opt(rodent_setup, rodent_mocap):
     """fit_offsets semantics: one chain continued across calls with q_init (stac.py:298-311)."""
     fs = rodent_setup
