@@ -71,7 +71,7 @@ struct stac_model {
     int32_t *d_ctl = nullptr;    // straggler hand-off: {finished, threshold, handed off, capacity}
     float *d_hand = nullptr;     // [hand_cap][3 nqpad + 12] solver states in transit
     int hand_cap = 0;
-    int32_t h_ctl[4] = {0, 0, 0, 0};
+    int32_t h_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float *d_scratch = nullptr;  // grown on demand (xpos/xquat when the caller does not want them)
     size_t scratch_floats = 0;
     int max_depth = 0;
@@ -639,6 +639,25 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
             if (const char *w = getenv("STAC_HIP_HANDOFF")) hcap = spec_cap ? std::min(std::max(atoi(w), 0), nchains) : 0;
         }
+        // Chain queue: when the launch has more chains than resident slots, the grid covers the resident slots only and
+        // a group that finishes a chain takes the next unstarted one -- no slot idles until its whole workgroup is done.
+        const long resident = (long)sh.waves_per_cu * kCus * (64 / G);
+        int qslots = 0;
+        if (!a.single && (long)nchains > resident && !(getenv("STAC_HIP_QUEUE") && atoi(getenv("STAC_HIP_QUEUE")) == 0)) qslots = (int)resident;
+        if (const char *w = getenv("STAC_HIP_QUEUE")) {  // developer / test override: this many slots (whole workgroups)
+            const int per_block = sh.wpb * (64 / G), want = atoi(w);
+            if (!a.single && want > 0 && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
+        }
+        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= 8 && !getenv("STAC_HIP_HANDOFF")) {
+            const QShape ss = pick_shape(m->h, 8, nkinds);
+            hcap = std::min(ss.wpb ? ss.waves_per_cu * kCus : 0, nchains / 5);  // with a queue the tail is one round: hand off
+        }
+        if (hcap > 0 || qslots > 0) {
+            if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
+            m->h_ctl[0] = 0; m->h_ctl[1] = hcap > 0 ? nchains - hcap : 0x7fffffff; m->h_ctl[2] = 0; m->h_ctl[3] = hcap; m->h_ctl[4] = qslots;
+            a.ctl = m->d_ctl;
+            a.queue_slots = qslots;
+        }
         if (hcap > 0) {
             const size_t hstride = 3 * (size_t)m->h.nqpad + 12;
             if (hcap > m->hand_cap) {
@@ -647,11 +666,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)hcap * hstride * sizeof(float)));
                 m->hand_cap = hcap;
             }
-            if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 4 * sizeof(int32_t)));
-            m->h_ctl[0] = 0; m->h_ctl[1] = nchains - hcap; m->h_ctl[2] = 0; m->h_ctl[3] = hcap;
-            HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
-            a.ctl = m->d_ctl; a.hand = m->d_hand;
+            a.hand = m->d_hand;
         }
+        if (a.ctl) HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
         if (cap && e == hipSuccess && hcap > 0) {
             // second launch: the latency kernel resumes whatever was handed off (waves without an entry exit at once)
@@ -668,7 +685,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
             if (getenv("STAC_HIP_VERBOSE")) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.wpb);
         }
-        a.ctl = nullptr; a.hand = nullptr;
+        a.ctl = nullptr; a.hand = nullptr; a.queue_slots = 0;
         if (cap) break;  // an instantiation with this many lanes holds nq
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");

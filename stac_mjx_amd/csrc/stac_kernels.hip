@@ -26,6 +26,8 @@
 // tests/test_gpu_parity.py checks exactly that.  There is no dense contraction on this path, hence no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "stac_plan.hpp"
 #include "stac_device.hpp"
 
@@ -90,8 +92,8 @@ void q_phase_kernel(const QArgs a) {
     const bool resuming = a.resume != 0 && slot_id < a.ctl[2] && slot_id < a.ctl[3];
     const float *hs = a.hand + (size_t)(resuming ? slot_id : 0) * hstride;
     const int *hi = reinterpret_cast<const int *>(hs + 3 * nqpad);
-    const int chain = a.resume ? (resuming ? hi[0] : a.C) : slot_id;
-    const int role = grp;  // SPEC: 0-3 candidate c, 4-7 momentum point of candidate c
+    int chain = a.resume ? (resuming ? hi[0] : a.C) : slot_id;  // with a chain queue (QArgs::queue_slots) a group takes
+    const int role = grp;                                        // further chains when it has finished one
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
     int frame = 0, iter = 0, nls = 0;
@@ -114,7 +116,7 @@ void q_phase_kernel(const QArgs a) {
     if (lg == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 0.f; bx[3] = 1.f; bx[4] = 0.f; bx[5] = 0.f; bx[6] = 0.f; }
 
     // initial qpos, keypoints of frame 0, first solve
-    const size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
+    size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
 #pragma unroll
     for (int r = 0; r < NQR; ++r) {
         const int e = r * G + lg;
@@ -134,6 +136,25 @@ void q_phase_kernel(const QArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; }
+    // the same for the next chain a group takes from the queue (all lanes of the group call it together)
+    auto begin_chain = [&](const int c) {
+        chain = c;
+        kp_chain = (size_t)c * a.F * 3 * K;
+        kind = a.do_root_opt ? 0 : 2;
+        frame = 0; iter = 0; nls = 0;
+        stepsize = 1.0f; t = 1.0f; error = __builtin_inff();
+        c_iter = c_ls = c_grad = c_solves = 0;
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            float v = 0.f;
+            if (e < nq) v = a.q_init ? a.q_init[(size_t)c * nq + e] : qpos0[e];
+            if (kind < 2 && e < 3) v = a.kp[kp_chain + 3 * a.root_kp_idx + e];
+            q0[r] = v; x[r] = v; y[r] = v; g[r] = 0.f;
+        }
+        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + i];
+        st = ST_VG_Y;
+    };
     if (resuming) {
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
@@ -626,7 +647,15 @@ void q_phase_kernel(const QArgs a) {
                             if (a.q_carry_out && (!SPEC || role == 0))
                                 for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
                             st = ST_DONE;
-                            if (!SPEC && a.ctl && lg == 0) atomicAdd(a.ctl, 1);  // finished chains (hand-off threshold)
+                            if (!SPEC && a.ctl) {
+                                if (lg == 0) atomicAdd(a.ctl, 1);  // finished chains (hand-off threshold)
+                                if (a.queue_slots > 0) {           // chain queue: take the next unstarted chain
+                                    int nxt = 0;
+                                    if (lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
+                                    nxt = __shfl(nxt, grp * G, 64);
+                                    if (nxt < a.C) begin_chain(nxt);
+                                }
+                            }
                         } else {
                             for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
                         }
@@ -785,7 +814,8 @@ template <int G, int NQR, int WPE, bool SPEC>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = SPEC ? 1 : 64 / G;
     const int per_block = CPW * wpb;
-    const int slots = a.resume ? a.resume_slots : a.C;  // a resume launch has one slot per hand-off entry
+    // a resume launch has one slot per hand-off entry; with a chain queue the grid covers the resident slots only
+    const int slots = a.resume ? a.resume_slots : (a.queue_slots > 0 ? std::min(a.queue_slots, a.C) : a.C);
     const int blocks = (slots + per_block - 1) / per_block;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE, SPEC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

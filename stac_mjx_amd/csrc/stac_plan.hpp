@@ -136,10 +136,12 @@ struct QArgs {
     // chains, capacity}: a chain of the throughput kernel that starts an iteration (state VG_Y) after `finished`
     // has reached `threshold` writes its solver state to hand[] and stops; a second launch of the latency kernel
     // (resume = 1, one chain per wavefront) picks the states up and finishes them, one trip per iteration.
-    int32_t *ctl;
+    int32_t *ctl;           // {finished, threshold, handed off, capacity, next chain of the queue}
     float *hand;            // [capacity][3 * nqpad + 12]: x, y, q0, then {chain, kind, frame, iter, stepsize, t, c_iter, c_ls, c_grad, c_solves, fx, error}
     int32_t resume;
     int32_t resume_slots;   // grid size of the resume launch (= capacity)
+    int32_t queue_slots;    // > 0: chain queue -- the grid covers this many chain slots (the resident ones); a group that
+                            // finishes a chain takes the next unstarted one (ctl[4]) instead of leaving its slot idle
     int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program (A/B switches)
     float tol;
     int32_t maxiter, maxls;

@@ -190,6 +190,24 @@ def test_q_phase_straggler_handoff(rodent_setup, rodent_mocap, monkeypatch, fram
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
 
 
+@pytest.mark.parametrize("handoff", [None, "10"])
+def test_q_phase_chain_queue(rodent_setup, rodent_mocap, monkeypatch, handoff):
+    """More chains than chain slots: the grid covers the slots and a group that finishes a chain takes the next
+    unstarted one from a device counter (forced here: 16 slots for 50 chains), with and without the straggler
+    hand-off on top.  Which group ran which chain must not matter: everything equals the oracle."""
+    monkeypatch.setenv("STAC_HIP_QUEUE", "16")
+    if handoff:
+        monkeypatch.setenv("STAC_HIP_HANDOFF", handoff)
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=16, maxiter=40), _oracle(fs, maxiter=40)
+    kp = rodent_mocap[100:200].reshape(50, 2, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(res, ref)
+    np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
+
+
 def test_q_phase_carried_chain_no_root_opt(rodent_setup, rodent_mocap):
     """fit_offsets semantics: one chain continued across calls with q_init (stac.py:298-311)."""
     fs = rodent_setup
