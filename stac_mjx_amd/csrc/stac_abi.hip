@@ -879,7 +879,22 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
         if (getenv("STAC_HIP_VERBOSE"))
             fprintf(stderr, "[stac] q_phase LM: chains=%d G=%d wpb=%d waves/CU=%d lds=%zu B/block chain_stride=%d n_max=%d maxpd=%d\n",
                     nchains, G, wpb, best_waves, lds_for(wpb), L.chain_stride, L.n_max, L.maxpd);
+        // chain queue (see run_q): the grid covers the resident slots, finished groups take the next chain
+        a.ctl = nullptr; a.queue_slots = 0;
+        long resident = (long)best_waves * kCus * cpw;
+        if (const char *w = getenv("STAC_HIP_QUEUE")) {  // developer / test override: this many slots (whole workgroups)
+            const int per_block = wpb * cpw, want = atoi(w);
+            if (want > 0 && want < nchains) resident = (long)(want + per_block - 1) / per_block * per_block;
+        }
+        if ((long)nchains > resident && !(getenv("STAC_HIP_QUEUE") && atoi(getenv("STAC_HIP_QUEUE")) == 0)) {
+            if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
+            for (int i = 0; i < 8; ++i) m->h_ctl[i] = 0;
+            m->h_ctl[4] = (int32_t)resident;
+            HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
+            a.ctl = m->d_ctl; a.queue_slots = (int)resident;
+        }
         e = launch_q_phase_lm(a, L, G, wpb, lds_for(wpb), s, &cap);
+        a.ctl = nullptr; a.queue_slots = 0;
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the LM q_phase kernel limits (LDS per CU / nq)");
     if (e != hipSuccess) return fail(STAC_ERR_HIP, std::string("q_phase LM launch: ") + hipGetErrorString(e));

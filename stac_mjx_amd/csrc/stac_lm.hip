@@ -101,7 +101,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     const float *lbv = P + H.off_lb, *ubv = P + H.off_ub, *qpos0 = P + H.off_qpos0;
     const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
-    const int chain = (blockIdx.x * wpb + wave) * CPW + grp;
+    int chain = (blockIdx.x * wpb + wave) * CPW + grp;  // with a chain queue (QArgs::queue_slots): the first of several
     int st = chain < a.C ? LM_EVAL_X : LM_DONE;
     int kind = a.do_root_opt ? 0 : 2;
     int frame = 0, iter = 0, tries = 0;
@@ -110,7 +110,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     float x[NQR], g[NQR], tr[NQR], q0[NQR];
 
     if (lg == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 0.f; bx[3] = 1.f; bx[4] = 0.f; bx[5] = 0.f; bx[6] = 0.f; }
-    const size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
+    size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
 #pragma unroll
     for (int r = 0; r < NQR; ++r) {
         const int e = r * G + lg;
@@ -497,6 +497,28 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                         if (a.q_carry_out)
                             for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
                         st = LM_DONE;
+                        if (a.queue_slots > 0) {  // chain queue: take the next unstarted chain (ctl[4])
+                            int nxt = 0;
+                            if (lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
+                            nxt = __shfl(nxt, grp * G, 64);
+                            if (nxt < a.C) {
+                                chain = nxt;
+                                kp_chain = (size_t)nxt * a.F * 3 * K;
+                                kind = a.do_root_opt ? 0 : 2;
+                                frame = 0;
+#pragma unroll
+                                for (int r = 0; r < NQR; ++r) {
+                                    const int e = r * G + lg;
+                                    float v = 0.f;
+                                    if (e < nq) v = a.q_init ? a.q_init[(size_t)nxt * nq + e] : qpos0[e];
+                                    if (kind < 2 && e < 3) v = a.kp[kp_chain + 3 * a.root_kp_idx + e];
+                                    q0[r] = v;
+                                    g[r] = 0.f;
+                                }
+                                for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + i];
+                                st = LM_EVAL_X;  // x, tr and the solver scalars are reset just below
+                            }
+                        }
                     } else {
                         for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
                     }
@@ -526,7 +548,8 @@ template <int G, int NQR, int WPE>
 static hipError_t launch_lm(const QArgs &a, const LmArgs &L, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = 64 / G;
     const int per_block = CPW * wpb;
-    const int blocks = (a.C + per_block - 1) / per_block;
+    const int slots = a.queue_slots > 0 ? (a.queue_slots < a.C ? a.queue_slots : a.C) : a.C;  // chain queue: resident slots only
+    const int blocks = (slots + per_block - 1) / per_block;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_lm_kernel<G, NQR, WPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;

@@ -516,6 +516,23 @@ def test_lm_q_phase_matches_oracle_lm_in_marker_space(rodent_setup, rodent_mocap
     assert it < 60, it
 
 
+def test_lm_chain_queue_same_as_static_assignment(rodent_setup, rodent_mocap, monkeypatch):
+    """LM kernel with the chain queue forced (8 slots for 30 chains): which group ran which chain must not matter --
+    identical outputs to the launch where every chain has its own slot."""
+    from stac_mjx_amd.engine import Engine
+
+    fs = rodent_setup
+    kp = rodent_mocap[0:60].reshape(30, 2, 69)
+    outs = []
+    for q in ("0", "8"):
+        monkeypatch.setenv("STAC_HIP_QUEUE", q)
+        eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, solver="lm", lm_maxiter=40)
+        outs.append(eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                                root_dims=fs.root_dims, do_root_opt=True))
+    for k in ("qpos", "frame_error", "counters", "marker_sites", "carry_qpos"):
+        assert (outs[0][k] == outs[1][k]).all(), k
+
+
 # ---- random models: the plan builder (levels, positions, stored transforms, step program) on arbitrary trees ------------
 def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_bias=0.6):
     """A random kinematic tree as ModelTables: depth-first body order, 0-3 joints per body (mostly hinges, some with
