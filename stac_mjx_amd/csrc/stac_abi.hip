@@ -547,11 +547,10 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 
 // Lanes per chain.  Fewer lanes = more chains per wave instruction (throughput); more lanes = fewer idle lanes
 // when there are few chains (latency).  Measured on the rodent (20-frame clips, frames/s in thousands):
-//   chains      500   1000   1500   2000   3000   5000   8000
-//   latency     63    123    168    125    170    158      -      (speculative kernel, 1536 chains resident)
-//   G = 64      34     68     90    120    126    150      -
-//   G = 32      31     59     86    115    155    216      -
-//   G = 16      25     51     72     96    140    212    334
+//   chains      500   1000   1500   2000   3000   4000   5000   8000
+//   latency     63    123    165    126    167    168    160      -      (speculative kernel, 1536 chains resident)
+//   G = 32      31     59     91    122    168    223    250      -
+//   G = 16      25     51     76    102    149    199    239    362
 // i.e. the latency mode up to about 2.3 x its resident capacity, then 32 lanes until the 16-lane kernel has
 // about 45 % of its slots filled (8 and 4 lanes only on request: with the LDS footprint of a chain they cannot
 // keep two waves per SIMD resident).  Returns 0 for the latency mode.
@@ -601,7 +600,23 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 fprintf(stderr, "[stac] q_phase: chains=%d speculative (1 chain per wavefront) wpb=%d lds=%zu B/block\n",
                         nchains, sh.wpb, q_lds_bytes(m->h, 8, nkinds, sh.wpb));
             a.mb_words = q_mb_words(nkinds, 8);
+            // chain queue (see below): more clips than resident wavefronts -> a wave that finishes its clip takes the next
+            const QShape sres = pick_shape(m->h, 8, nkinds);
+            long resident = (long)sres.waves_per_cu * kCus / sh.wpb * sh.wpb;
+            if (const char *w = getenv("STAC_HIP_QUEUE")) {
+                const int want = atoi(w);
+                if (want > 0 && want < nchains) resident = (long)(want + sh.wpb - 1) / sh.wpb * sh.wpb;
+            }
+            if ((long)nchains > resident && !(getenv("STAC_HIP_QUEUE") && atoi(getenv("STAC_HIP_QUEUE")) == 0)) {
+                if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
+                for (int i = 0; i < 8; ++i) m->h_ctl[i] = 0;
+                m->h_ctl[1] = 0x7fffffff;
+                m->h_ctl[4] = (int32_t)resident;
+                HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
+                a.ctl = m->d_ctl; a.queue_slots = (int)resident;
+            }
             e = launch_q_phase(a, 8, sh.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, sh.wpb), s, &cap);
+            a.ctl = nullptr; a.queue_slots = 0;
         }
     }
     for (; !cap && G <= 64; G *= 2) {

@@ -647,12 +647,12 @@ void q_phase_kernel(const QArgs a) {
                             if (a.q_carry_out && (!SPEC || role == 0))
                                 for (int e = lg; e < nq; e += G) a.q_carry_out[(size_t)chain * nq + e] = qe[e];
                             st = ST_DONE;
-                            if (!SPEC && a.ctl) {
-                                if (lg == 0) atomicAdd(a.ctl, 1);  // finished chains (hand-off threshold)
-                                if (a.queue_slots > 0) {           // chain queue: take the next unstarted chain
-                                    int nxt = 0;
-                                    if (lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
-                                    nxt = __shfl(nxt, grp * G, 64);
+                            if (a.ctl && !a.resume) {
+                                if (!SPEC && lg == 0) atomicAdd(a.ctl, 1);  // finished chains (hand-off threshold)
+                                if (a.queue_slots > 0) {  // chain queue: take the next unstarted chain (latency mode: the
+                                    int nxt = 0;          // whole wavefront, i.e. all eight groups, moves on together)
+                                    if (SPEC ? lane == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
+                                    nxt = __shfl(nxt, SPEC ? 0 : grp * G, 64);
                                     if (nxt < a.C) begin_chain(nxt);
                                 }
                             }
