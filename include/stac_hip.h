@@ -11,10 +11,12 @@
  *     as void*; NULL = the default stream).
  *   - every `float*` / `uint32_t*` data argument is a DEVICE pointer owned by the caller (e.g. a
  *     PyTorch-ROCm tensor) unless the comment says "host".  The library never frees caller memory.
- *   - all calls are asynchronous on `stream`; nothing synchronises the device.
+ *   - all calls are asynchronous on `stream`; nothing synchronises the device (the first stac_q_solve / stac_q_phase
+ *     call with a NEW set of masks waits once for its own small table uploads on that stream).
  *   - return value: 0 = OK, negative = error (see stac_last_error()); no exceptions cross the ABI.
  *   - layouts are C-contiguous float32; clip-major: kp[C][F][3K], qpos[C][F][nq].
- *   - re-entrant per stac_model; no global state besides the thread-local error string.
+ *   - re-entrant per stac_model (one call at a time per model: it owns scratch buffers for the launch in flight);
+ *     no global state besides the thread-local error string.
  */
 #ifndef STAC_HIP_H
 #define STAC_HIP_H
