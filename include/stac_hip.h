@@ -15,7 +15,8 @@
  *     call with a NEW set of masks waits once for its own small table uploads on that stream).
  *   - return value: 0 = OK, negative = error (see stac_last_error()); no exceptions cross the ABI.
  *   - layouts are C-contiguous float32; clip-major: kp[C][F][3K], qpos[C][F][nq].
- *   - re-entrant per stac_model (one call at a time per model: it owns scratch buffers for the launch in flight);
+ *   - re-entrant per model: one call at a time on a given stac_model, which owns scratch buffers for the launch in
+ *     flight;
  *     no global state besides the thread-local error string.
  */
 #ifndef STAC_HIP_H
