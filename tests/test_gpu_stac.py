@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
+from helpers import oracle_fit_offsets as _oracle_fit_offsets
 
 pytestmark = pytest.mark.gpu
 
@@ -19,34 +20,16 @@ def _cfg(rodent_cfg, **stac_over):
     return validate_config({"model": dict(rodent_cfg), "stac": stac})
 
 
-def _oracle_fit_offsets(fs, cfgm, kp, n_iters):
-    """Test-side restatement of Stac.fit_offsets (stac.py:253-354) driven by the CPU oracle."""
-    from oracle import Oracle
-    from stac_mjx_amd.prng import sample_time_indices
-
-    orc = Oracle(fs.tables, tol=float(cfgm["FTOL"]), maxiter=int(cfgm["N_ITER_Q"]))
-    offsets = fs.tables.site_pos.copy()
-    q, _ = orc.root_optimization(kp, fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
-    idx = sample_time_indices(kp.shape[0], int(cfgm["N_SAMPLE_FRAMES"]))
-    for _ in range(n_iters):
-        out = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
-        q = out["carry_qpos"]
-        offsets, _ = orc.m_opt(kp[idx], out["qpos"][idx], offsets, fs.is_regularized, float(cfgm["M_REG_COEF"]))
-        orc.set_site_pos(offsets)
-    out = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
-    return offsets, out
-
-
 def test_fit_offsets_config1_bit_exact(rodent_setup, rodent_cfg, rodent_mocap):
     """BASELINE config 1: real mocap, n_fit_frames=10, offset/pose alternation."""
     from stac_mjx_amd.stac import Stac
 
     cfg = _cfg(rodent_cfg)
-    cfg.model.N_ITERS = 2  # keeps the CPU oracle side short; the alternation logic is the same
+    assert int(cfg.model.N_ITERS) == 6  # configs/model/rodent.yaml: the real alternation count
     kp = rodent_mocap[:10]
     stac = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False)
     data = stac.fit_offsets(kp)
-    ref_off, ref = _oracle_fit_offsets(rodent_setup, rodent_cfg, kp, 2)
+    ref_off, ref = _oracle_fit_offsets(rodent_setup, rodent_cfg, kp, 6)
     np.testing.assert_array_equal(data.offsets, ref_off)
     np.testing.assert_array_equal(data.qpos, ref["qpos"])
     np.testing.assert_array_equal(data.marker_sites, ref["marker_sites"])
