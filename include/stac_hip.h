@@ -11,8 +11,16 @@
  *     as void*; NULL = the default stream).
  *   - every `float*` / `uint32_t*` data argument is a DEVICE pointer owned by the caller (e.g. a
  *     PyTorch-ROCm tensor) unless the comment says "host".  The library never frees caller memory.
- *   - all calls are asynchronous on `stream`; nothing synchronises the device (the first stac_q_solve / stac_q_phase
- *     call with a NEW set of masks waits once for its own small table uploads on that stream).
+ *   - all calls are asynchronous on `stream`.  Host-side waits, complete list: (1) a stac_q_solve / stac_q_phase
+ *     call with a NEW set of masks (or stac_q_solve with new lb / ub) waits once for its own small table uploads
+ *     on that stream (the host arrays are the caller's temporaries); (2) stac_fk / stac_q_phase called WITHOUT
+ *     xpos / xquat outputs grow an internal scratch block to its high-water mark -- growing frees the old block,
+ *     which waits for the device.  Launch control words are set by a kernel on the stream, every other buffer is
+ *     allocated at stac_model_create.
+ *   - a model belongs to the device that was current at stac_model_create; every entry point makes that device
+ *     current for its duration and restores the caller's.
+ *   - developer switches (STAC_HIP_* environment variables) are read once, at
+ *     stac_model_create.
  *   - return value: 0 = OK, negative = error (see stac_last_error()); no exceptions cross the ABI.
  *   - layouts are C-contiguous float32; clip-major: kp[C][F][3K], qpos[C][F][nq].
  *   - re-entrant per model: one call at a time on a given stac_model, which owns scratch buffers for the launch in
@@ -28,7 +36,7 @@
 extern "C" {
 #endif
 
-#define STAC_HIP_ABI_VERSION 2
+#define STAC_HIP_ABI_VERSION 3
 
 /* mjtJoint values (same as MuJoCo's, so tables from a MuJoCo compile can be passed as they are). */
 enum { STAC_JNT_FREE = 0, STAC_JNT_BALL = 1, STAC_JNT_SLIDE = 2, STAC_JNT_HINGE = 3 };
@@ -106,12 +114,14 @@ int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, float *qpos_n
 
 /* Batched StacCore.q_opt (stac_mjx/stac_core.py:193-235): N independent solves with the same masks.
  *   kp[N,3K], q0[N,nq]; qs_to_opt[nq] and kps_to_opt[3K] are HOST uint8 masks.
+ *   lb[nq], ub[nq]: HOST float box of THIS call, as q_opt takes it per call (hyperparams_proj, stac_core.py:83);
+ *   both NULL = the bounds given at stac_model_create.
  *   params_out[N,nq]  = res.params (not blended with q0 -- the caller applies make_qs)
  *   state_out[N,4]    = {error, stepsize, t, loss(params)}   (res.state)
  *   counters_out[N,4] = {iter_num, ls_evals, grad_evals, 1}  (may be NULL) */
 int32_t stac_q_solve(const stac_model *m, const stac_q_params *p, const float *kp, const float *q0,
-                     const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, int32_t N,
-                     float *params_out, float *state_out, uint32_t *counters_out, void *stream);
+                     const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const float *lb, const float *ub,
+                     int32_t N, float *params_out, float *state_out, uint32_t *counters_out, void *stream);
 
 /* The q_phase of C clips of F frames each, one warm-started chain per clip: per clip
  * [root_optimization on frame 0 (compute_stac.py:17-104) if do_root_opt] then pose_optimization

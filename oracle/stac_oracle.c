@@ -519,7 +519,8 @@ void orc_m_finish(int32_t K, const float *partial, const float *initial_offsets,
         const real d = R(is_regularized[i]), s = R(partial[i]), m0 = R(initial_offsets[i]);
         const real denom = T + lam * d;
         const real numer = s + lam * d * m0;
-        const real ms_i = numer / denom;
+        /* no frame at all and an unregularised coordinate: keep the previous offset (the reference would divide 0 by 0) */
+        const real ms_i = denom == (real)0 ? m0 : numer / denom;
         params_out[i] = (float)ms_i;
         ms += ms_i * s;
         mm += ms_i * ms_i;

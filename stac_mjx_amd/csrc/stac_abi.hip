@@ -27,6 +27,7 @@ hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xp
                             float *contrib, float *partial, hipStream_t s);
 hipError_t launch_m_finish(int K, const float *partial, const float *m0, const float *dreg, float lam, float *out,
                            float *err, hipStream_t s);
+hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4, hipStream_t s);
 }  // namespace stac
 
 using namespace stac;
@@ -43,7 +44,27 @@ static int fail(int code, const std::string &msg) {
             return fail(STAC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));       \
     } while (0)
 
+// Developer switches: read from the environment ONCE, at stac_model_create, so that a variable
+// set later cannot change the launch shape of a model in use.  -1 = not set.
+struct DebugSwitches {
+    int flags = -1, spec = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
+    bool noprune = false, verbose = false;
+    static int geti(const char *name) {
+        const char *v = getenv(name);
+        return v ? atoi(v) : -1;
+    }
+    void read_env() {
+        flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
+        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE");
+        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
+    }
+};
+
 struct stac_model {
+    int device = 0;   // the HIP device the model lives on: every entry point runs with it current (and restores)
+    DebugSwitches dbg;
+    float *d_bounds = nullptr;          // [2 nqpad] per-call lb / ub of stac_q_solve
+    std::vector<float> bounds_cache;    // what d_bounds holds
     PlanHeader h{};
     std::vector<float> blob_host;  // plan blob (host mirror)
     float *d_blob = nullptr;       // device plan blob
@@ -71,7 +92,6 @@ struct stac_model {
     int32_t *d_ctl = nullptr;    // straggler hand-off: {finished, threshold, handed off, capacity}
     float *d_hand = nullptr;     // [hand_cap][3 nqpad + 12] solver states in transit
     int hand_cap = 0;
-    int32_t h_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float *d_scratch = nullptr;  // grown on demand (xpos/xquat when the caller does not want them)
     size_t scratch_floats = 0;
     int max_depth = 0;
@@ -96,11 +116,28 @@ static hipError_t upload(T **dst, const T *src, size_t n) {
     return e;
 }
 
+// Makes the model's device current for the duration of an entry point (a caller may have switched devices since
+// stac_model_create: allocations and launches must still land on the model's GPU), then restores the caller's.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const stac_model *m) {
+        if (m && hipGetDevice(&prev) == hipSuccess && prev != m->device) switched = hipSetDevice(m->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// Scratch for stac_fk / stac_q_phase when the caller does not want xpos / xquat: kept at its high-water mark (grown
+// by half again, so repeated slightly larger calls do not reallocate).  Growing frees the old block, which waits for
+// the device -- the only such wait of the library, documented in stac_hip.h.
 static int ensure_scratch(stac_model *m, size_t floats) {
     if (floats <= m->scratch_floats) return STAC_OK;
     if (m->d_scratch) (void)hipFree(m->d_scratch);
     m->d_scratch = nullptr;
     m->scratch_floats = 0;
+    floats += floats / 2;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_scratch), floats * sizeof(float)));
     m->scratch_floats = floats;
     return STAC_OK;
@@ -459,6 +496,8 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
         return nullptr;
     }
     stac_model *m = new stac_model();
+    (void)hipGetDevice(&m->device);
+    m->dbg.read_env();
     if (build_plan(m, t) != STAC_OK) { delete m; return nullptr; }
     const int nb = t->nbody, nj = t->njnt, nq = t->nq, K = t->nsite;
     hipError_t e = hipSuccess;
@@ -478,6 +517,15 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     chk(upload(&m->d_site_pos, t->site_pos, (size_t)K * 3));
     m->masks_bytes = (size_t)kMaxKinds * m->h.nqpad + 4 * (size_t)K + 64;
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_masks), m->masks_bytes));
+    chk(hipMalloc(reinterpret_cast<void **>(&m->d_bounds), 2 * (size_t)m->h.nqpad * sizeof(float)));
+    chk(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
+    {   // hand-off buffer of the straggler hand-off at its maximum size (one entry per wavefront the latency kernel
+        // can hold resident), so that no launch ever reallocates (= waits for the device)
+        const QShape ss = pick_shape(m->h, 8, 1);
+        m->hand_cap = ss.wpb ? ss.waves_per_cu * kCus : 0;
+        if (m->hand_cap > 0)
+            chk(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)m->hand_cap * (3 * (size_t)m->h.nqpad + 12) * sizeof(float)));
+    }
     if (e != hipSuccess) {
         fail(STAC_ERR_HIP, std::string("model upload failed: ") + hipGetErrorString(e));
         stac_model_destroy(m);
@@ -489,7 +537,8 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
 
 extern "C" void stac_model_destroy(stac_model *m) {
     if (!m) return;
-    void *ptrs[] = {m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
+    DeviceGuard dg(m);
+    void *ptrs[] = {m->d_bounds, m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
                     m->d_body_quat, m->d_jnt_type, m->d_jnt_qposadr, m->d_jnt_pos, m->d_jnt_axis,
                     m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab, m->d_ctl, m->d_hand};
     for (void *p : ptrs)
@@ -510,6 +559,7 @@ extern "C" int32_t stac_model_info(const stac_model *m, int32_t *info) {
 
 extern "C" int32_t stac_set_site_pos(stac_model *m, const float *offsets, void *stream) {
     if (!m || !offsets) return fail(STAC_ERR_INVALID, "null argument");
+    DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(m->d_site_pos, offsets, sizeof(float) * 3 * m->h.K, hipMemcpyDeviceToDevice, s));
     // scatter into the plan's SiteRec.pos (stride 4 words)
@@ -520,6 +570,7 @@ extern "C" int32_t stac_set_site_pos(stac_model *m, const float *offsets, void *
 
 extern "C" int32_t stac_get_site_pos(const stac_model *m, float *out, void *stream) {
     if (!m || !out) return fail(STAC_ERR_INVALID, "null argument");
+    DeviceGuard dg(m);
     HIP_TRY(hipMemcpyAsync(out, m->d_site_pos, sizeof(float) * 3 * m->h.K, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return STAC_OK;
 }
@@ -529,6 +580,7 @@ static int fk_impl(const stac_model *mc, const float *qpos, int32_t N, float *qn
     stac_model *m = const_cast<stac_model *>(mc);
     if (!m || !qpos || N < 0) return fail(STAC_ERR_INVALID, "stac_fk: bad argument");
     if (N == 0) return STAC_OK;
+    DeviceGuard dg(m);
     const size_t nb = m->h.nbody;
     if (!xpos || !xquat) {
         const int rc = ensure_scratch(m, (size_t)N * nb * 7);
@@ -575,7 +627,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     a.h = m->h;
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const int nkinds = a.single ? 1 : a.P + 3;
-    if (const char *f = getenv("STAC_HIP_FLAGS")) a.flags = atoi(f);  // developer A/B switches (see stac_plan.hpp)
+    const DebugSwitches &dbg = m->dbg;
+    if (dbg.flags >= 0) a.flags = dbg.flags;  // developer A/B switches (see stac_plan.hpp)
 #ifdef STAC_PROFILE
     static unsigned long long *d_prof = nullptr;
     if (!d_prof) { (void)hipMalloc(reinterpret_cast<void **>(&d_prof), 16 * sizeof(unsigned long long)); }
@@ -589,30 +642,23 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     // the wavefront's eight 8-lane groups evaluate the line-search candidates and next momentum points of
     // that ONE chain speculatively (q_phase_kernel<8, ., ., true>): one trip per iteration instead of three.
     int spec = G == 0 ? 1 : 0;
-    if (const char *w = getenv("STAC_HIP_SPEC")) spec = a.single ? 0 : atoi(w);
+    if (dbg.spec >= 0) spec = a.single ? 0 : dbg.spec;
     if (G == 0) G = spec ? 64 : 32;
     if (spec) {
         QShape sh = pick_shape(m->h, 8, nkinds, nchains);  // 8 groups of 8 lanes: same LDS as eight 8-lane chains
         if (sh.wpb) {
             sh.wpe = 2;
             while (sh.wpb > 1 && q_lds_bytes(m->h, 8, nkinds, sh.wpb) > kLdsPerCu) --sh.wpb;
-            if (getenv("STAC_HIP_VERBOSE"))
+            if (dbg.verbose)
                 fprintf(stderr, "[stac] q_phase: chains=%d speculative (1 chain per wavefront) wpb=%d lds=%zu B/block\n",
                         nchains, sh.wpb, q_lds_bytes(m->h, 8, nkinds, sh.wpb));
             a.mb_words = q_mb_words(nkinds, 8);
             // chain queue (see below): more clips than resident wavefronts -> a wave that finishes its clip takes the next
             const QShape sres = pick_shape(m->h, 8, nkinds);
             long resident = (long)sres.waves_per_cu * kCus / sh.wpb * sh.wpb;
-            if (const char *w = getenv("STAC_HIP_QUEUE")) {
-                const int want = atoi(w);
-                if (want > 0 && want < nchains) resident = (long)(want + sh.wpb - 1) / sh.wpb * sh.wpb;
-            }
-            if ((long)nchains > resident && !(getenv("STAC_HIP_QUEUE") && atoi(getenv("STAC_HIP_QUEUE")) == 0)) {
-                if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
-                for (int i = 0; i < 8; ++i) m->h_ctl[i] = 0;
-                m->h_ctl[1] = 0x7fffffff;
-                m->h_ctl[4] = (int32_t)resident;
-                HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
+            if (dbg.queue > 0 && dbg.queue < nchains) resident = (long)(dbg.queue + sh.wpb - 1) / sh.wpb * sh.wpb;
+            if ((long)nchains > resident && dbg.queue != 0) {
+                HIP_TRY(launch_ctl_init(m->d_ctl, 0, 0x7fffffff, 0, 0, (int)resident, s));
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
             e = launch_q_phase(a, 8, sh.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, sh.wpb), s, &cap);
@@ -627,19 +673,19 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         QShape sh = pick_shape(a.h, G, nkinds, waves_needed);
         if (!sh.wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
         a.flags |= 2;
-        if (m->h.max_width <= G && !(getenv("STAC_HIP_FLAGS") && (atoi(getenv("STAC_HIP_FLAGS")) & 2))) {
+        if (m->h.max_width <= G && !(dbg.flags >= 0 && (dbg.flags & 2))) {
             PlanHeader hp = m->h;
             const QShape shp = pick_shape(hp, G, nkinds, waves_needed);
             if (shp.wpb && (shp.waves_per_cu >= sh.waves_per_cu || (long)shp.waves_per_cu * kCus >= waves_needed)) {
                 sh = shp; a.h.total_words = m->h.total_words; a.flags &= ~2;  // same residency, or every wave resident anyway
             }
         }
-        if (const char *w = getenv("STAC_HIP_WPE")) sh.wpe = atoi(w) >= 4 ? 4 : (atoi(w) == 3 && G == 16) ? 3 : 2;
-        if (const char *w = getenv("STAC_HIP_WPB")) {  // developer overrides
-            const int ww = atoi(w);
+        if (dbg.wpe >= 0) sh.wpe = dbg.wpe >= 4 ? 4 : (dbg.wpe == 3 && G == 16) ? 3 : 2;
+        if (dbg.wpb >= 0) {  // developer overrides
+            const int ww = dbg.wpb;
             if (ww >= 1 && ww <= (sh.wpe == 3 ? 10 : 8) && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
         }
-        if (getenv("STAC_HIP_VERBOSE"))
+        if (dbg.verbose)
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
                     nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), m->h.chain_stride, a.h.total_words);
         a.mb_words = q_mb_words(nkinds, G);
@@ -652,38 +698,32 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             const int spec_cap = ss.wpb ? ss.waves_per_cu * kCus : 0;
             // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
             if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
-            if (const char *w = getenv("STAC_HIP_HANDOFF")) hcap = spec_cap ? std::min(std::max(atoi(w), 0), nchains) : 0;
+            if (dbg.handoff >= 0) hcap = spec_cap ? std::min(dbg.handoff, nchains) : 0;
         }
         // Chain queue: when the launch has more chains than resident slots, the grid covers the resident slots only and
         // a group that finishes a chain takes the next unstarted one -- no slot idles until its whole workgroup is done.
         const long resident = (long)sh.waves_per_cu * kCus * (64 / G);
         int qslots = 0;
-        if (!a.single && (long)nchains > resident && !(getenv("STAC_HIP_QUEUE") && atoi(getenv("STAC_HIP_QUEUE")) == 0)) qslots = (int)resident;
-        if (const char *w = getenv("STAC_HIP_QUEUE")) {  // developer / test override: this many slots (whole workgroups)
-            const int per_block = sh.wpb * (64 / G), want = atoi(w);
-            if (!a.single && want > 0 && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
+        if (!a.single && (long)nchains > resident && dbg.queue != 0) qslots = (int)resident;
+        if (dbg.queue > 0) {  // developer / test override: this many slots (whole workgroups)
+            const int per_block = sh.wpb * (64 / G), want = dbg.queue;
+            if (!a.single && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
         }
-        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= 8 && !getenv("STAC_HIP_HANDOFF")) {
+        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= 8 && dbg.handoff < 0) {
             const QShape ss = pick_shape(m->h, 8, nkinds);
             hcap = std::min(ss.wpb ? ss.waves_per_cu * kCus : 0, nchains / 5);  // with a queue the tail is one round: hand off
         }
+        hcap = std::min(hcap, m->hand_cap);
+        // A group that hands its chain off stops taking chains from the queue, so hand-off must not begin while the
+        // queue could still hold more unstarted chains than the groups that stay: the threshold nchains - hcap is
+        // only reached after every chain has STARTED when hcap <= qslots (at most qslots chains are in flight).
+        if (qslots > 0) hcap = std::min(hcap, qslots);
         if (hcap > 0 || qslots > 0) {
-            if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
-            m->h_ctl[0] = 0; m->h_ctl[1] = hcap > 0 ? nchains - hcap : 0x7fffffff; m->h_ctl[2] = 0; m->h_ctl[3] = hcap; m->h_ctl[4] = qslots;
+            HIP_TRY(launch_ctl_init(m->d_ctl, 0, hcap > 0 ? nchains - hcap : 0x7fffffff, 0, hcap, qslots, s));
             a.ctl = m->d_ctl;
             a.queue_slots = qslots;
         }
-        if (hcap > 0) {
-            const size_t hstride = 3 * (size_t)m->h.nqpad + 12;
-            if (hcap > m->hand_cap) {
-                if (m->d_hand) (void)hipFree(m->d_hand);
-                m->d_hand = nullptr; m->hand_cap = 0;
-                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)hcap * hstride * sizeof(float)));
-                m->hand_cap = hcap;
-            }
-            a.hand = m->d_hand;
-        }
-        if (a.ctl) HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
+        if (hcap > 0) a.hand = m->d_hand;
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
         if (cap && e == hipSuccess && hcap > 0) {
             // second launch: the latency kernel resumes whatever was handed off (waves without an entry exit at once)
@@ -698,7 +738,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             int cap2 = 0;
             e = launch_q_phase(b, 8, ss.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, ss.wpb), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
-            if (getenv("STAC_HIP_VERBOSE")) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.wpb);
+            if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.wpb);
         }
         a.ctl = nullptr; a.hand = nullptr; a.queue_slots = 0;
         if (cap) break;  // an instantiation with this many lanes holds nq
@@ -883,7 +923,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
         // the FK program (stac_plan.hpp) is staged only if every level fits the lane group and it costs no occupancy
         a.flags |= 2;
         a.h.total_words = m->h.core_words;
-        if (m->h.max_width <= G && !(getenv("STAC_HIP_FLAGS") && (atoi(getenv("STAC_HIP_FLAGS")) & 2))) {
+        if (m->h.max_width <= G && !(m->dbg.flags >= 0 && (m->dbg.flags & 2))) {
             plan_words = m->h.total_words;
             int wpb2 = 0;
             const int waves2 = best_shape(wpb2);
@@ -891,21 +931,18 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
             else plan_words = m->h.core_words;
         }
         a.mb_words = mbw;
-        if (getenv("STAC_HIP_VERBOSE"))
+        if (m->dbg.verbose)
             fprintf(stderr, "[stac] q_phase LM: chains=%d G=%d wpb=%d waves/CU=%d lds=%zu B/block chain_stride=%d n_max=%d maxpd=%d\n",
                     nchains, G, wpb, best_waves, lds_for(wpb), L.chain_stride, L.n_max, L.maxpd);
         // chain queue (see run_q): the grid covers the resident slots, finished groups take the next chain
         a.ctl = nullptr; a.queue_slots = 0;
         long resident = (long)best_waves * kCus * cpw;
-        if (const char *w = getenv("STAC_HIP_QUEUE")) {  // developer / test override: this many slots (whole workgroups)
-            const int per_block = wpb * cpw, want = atoi(w);
-            if (want > 0 && want < nchains) resident = (long)(want + per_block - 1) / per_block * per_block;
+        if (m->dbg.queue > 0) {  // developer / test override: this many slots (whole workgroups)
+            const int per_block = wpb * cpw, want = m->dbg.queue;
+            if (want < nchains) resident = (long)(want + per_block - 1) / per_block * per_block;
         }
-        if ((long)nchains > resident && !(getenv("STAC_HIP_QUEUE") && atoi(getenv("STAC_HIP_QUEUE")) == 0)) {
-            if (!m->d_ctl) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
-            for (int i = 0; i < 8; ++i) m->h_ctl[i] = 0;
-            m->h_ctl[4] = (int32_t)resident;
-            HIP_TRY(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(m->h_ctl), hipMemcpyHostToDevice, s));
+        if ((long)nchains > resident && m->dbg.queue != 0) {
+            HIP_TRY(launch_ctl_init(m->d_ctl, 0, 0, 0, 0, (int)resident, s));
             a.ctl = m->d_ctl; a.queue_slots = (int)resident;
         }
         e = launch_q_phase_lm(a, L, G, wpb, lds_for(wpb), s, &cap);
@@ -935,7 +972,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
 static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enable, hipStream_t s) {
     const PlanHeader &h = m->h;
     m->n_mlev_root = 0;
-    if (!enable || getenv("STAC_HIP_NOPRUNE")) return STAC_OK;
+    if (!enable || m->dbg.noprune) return STAC_OK;
     std::vector<char> need(h.nab, 0);
     int n_need = 0;
     for (int k = 0; k < h.K; ++k)
@@ -952,15 +989,31 @@ static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enabl
 }
 
 extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, const float *kp, const float *q0,
-                                const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, int32_t N,
-                                float *params_out, float *state_out, uint32_t *counters_out, void *stream) {
+                                const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const float *lb, const float *ub,
+                                int32_t N, float *params_out, float *state_out, uint32_t *counters_out, void *stream) {
     stac_model *m = const_cast<stac_model *>(mc);
     if (!m || !p || !kp || !q0 || !qs_to_opt || !kps_to_opt || !params_out || !state_out || N < 0)
         return fail(STAC_ERR_INVALID, "stac_q_solve: bad argument");
+    if ((lb == nullptr) != (ub == nullptr)) return fail(STAC_ERR_INVALID, "stac_q_solve: lb and ub must be given together");
     if (N == 0) return STAC_OK;
     if (p->solver != STAC_SOLVER_PG) return fail(STAC_ERR_INVALID, "stac_q_solve implements the reference's projected gradient only");
+    DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
     const int nqpad = m->h.nqpad, K = m->h.K, nq = m->h.nq;
+    const float *d_bounds = nullptr;
+    if (lb) {  // per-call box (StacCore.q_opt takes lb / ub per call, stac_core.py:193-235); NULL = the model's
+        std::vector<float> hb(2 * (size_t)nqpad, 0.0f);
+        std::memcpy(hb.data(), lb, nq * sizeof(float));
+        std::memcpy(hb.data() + nqpad, ub, nq * sizeof(float));
+        for (int i = 0; i < nq; ++i)
+            if (!(hb[i] <= hb[nqpad + i])) return fail(STAC_ERR_INVALID, "stac_q_solve: lb > ub (or NaN) at coordinate " + std::to_string(i));
+        if (hb != m->bounds_cache) {
+            HIP_TRY(hipMemcpyAsync(m->d_bounds, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // hb is a temporary
+            m->bounds_cache = hb;
+        }
+        d_bounds = m->d_bounds;
+    }
     std::vector<uint8_t> hostm((size_t)nqpad + 3 * K + 1, 0);
     std::memcpy(hostm.data(), qs_to_opt, nq);
     std::memcpy(hostm.data() + nqpad, kps_to_opt, 3 * K);
@@ -975,6 +1028,7 @@ extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, co
     QArgs a{};
     a.kp = kp; a.q_init = q0; a.masks = m->d_masks; a.kpw = nullptr; a.kpw3 = d_kpw3;
     a.C = N; a.F = 1; a.P = 0; a.root_kp_idx = 0; a.do_root_opt = 0; a.single = 1;
+    a.bounds = d_bounds;
     a.qpos_out = params_out; a.err_out = state_out; a.counters_out = counters_out; a.q_carry_out = nullptr;
     return run_q(m, p, a, N, s);
 }
@@ -992,6 +1046,7 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     if (do_root_opt && (!trunk_kps || root_kp_idx < 0 || root_kp_idx >= m->h.K || root_dims < 1 || root_dims > m->h.nq))
         return fail(STAC_ERR_INVALID, "stac_q_phase: bad root optimisation arguments");
     if (C == 0 || F == 0) return STAC_OK;
+    DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
     const int nqpad = m->h.nqpad, K = m->h.K, nq = m->h.nq;
     // mask table: rows 0,1 = root passes (first root_dims qpos), row 2 = all, rows 3.. = parts
@@ -1047,6 +1102,7 @@ extern "C" int64_t stac_m_phase_workspace_floats(const stac_model *m, int32_t T)
 extern "C" int32_t stac_m_phase_partial(const stac_model *m, const float *kp, const float *q, int32_t T,
                                         float *workspace, float *partial, void *stream) {
     if (!m || !kp || !q || !workspace || !partial || T < 0) return fail(STAC_ERR_INVALID, "stac_m_phase_partial: bad argument");
+    DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
     const size_t nb = m->h.nbody;
     float *xpos = workspace, *xquat = workspace + (size_t)T * nb * 3, *contrib = workspace + (size_t)T * nb * 7;
@@ -1060,6 +1116,7 @@ extern "C" int32_t stac_m_phase_finish(const stac_model *m, const float *partial
                                        float *err_out, void *stream) {
     if (!m || !partial || !initial_offsets || !is_regularized || !offsets_out)
         return fail(STAC_ERR_INVALID, "stac_m_phase_finish: bad argument");
+    DeviceGuard dg(m);
     HIP_TRY(launch_m_finish(m->h.K, partial, initial_offsets, is_regularized, reg_coef, offsets_out, err_out,
                             (hipStream_t)stream));
     return STAC_OK;

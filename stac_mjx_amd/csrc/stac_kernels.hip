@@ -60,7 +60,14 @@ void q_phase_kernel(const QArgs a) {
 
     // ---- stage the plan into LDS (shared by the block's wavefronts) ------------------------------------
     float *P = lds;
-    for (int i = threadIdx.x; i < H.total_words; i += blockDim.x) P[i] = a.plan[i];
+    for (int i = threadIdx.x; i < H.total_words; i += blockDim.x) {
+        float v = a.plan[i];
+        if (a.bounds) {  // per-call lb / ub of stac_q_solve (StacCore.q_opt takes them per call, stac_core.py:193-235)
+            if (i >= H.off_lb && i < H.off_lb + nqpad) v = a.bounds[i - H.off_lb];
+            else if (i >= H.off_ub && i < H.off_ub + nqpad) v = a.bounds[nqpad + i - H.off_ub];
+        }
+        P[i] = v;
+    }
     const int plan_words = (H.total_words + 3) & ~3;
     // per-kind qs_to_opt bit masks, one 32-bit word per (kind, lane-in-group): bit r <-> element r*G+lg
     uint32_t *MB = reinterpret_cast<uint32_t *>(lds + plan_words);
@@ -797,7 +804,8 @@ __global__ void m_finish_kernel(int K, const float *partial, const float *m0, co
         const float d = dreg[i], s = partial[i], m0i = m0[i];
         const float denom = T + lam * d;
         const float numer = s + lam * d * m0i;
-        const float v = numer / denom;
+        // no frame anywhere and an unregularised coordinate: nothing determines it -- keep the previous offset
+        const float v = denom == 0.0f ? m0i : numer / denom;
         out[i] = v;
         ms += v * s;
         mm += v * v;
@@ -807,9 +815,19 @@ __global__ void m_finish_kernel(int K, const float *partial, const float *m0, co
     if (err) *err = ((z2 - 2.0f * ms) + T * mm) + lam * reg;
 }
 
+// control words of the chain queue / straggler hand-off (QArgs::ctl), set on the stream: no host buffer involved
+__global__ void ctl_init_kernel(int32_t *ctl, int v0, int v1, int v2, int v3, int v4) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[0] = v0; ctl[1] = v1; ctl[2] = v2; ctl[3] = v3; ctl[4] = v4; ctl[5] = 0; ctl[6] = 0; ctl[7] = 0; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (called from stac_abi.hip)
 // ------------------------------------------------------------------------------------------------
+hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4, hipStream_t s) {
+    hipLaunchKernelGGL(ctl_init_kernel, dim3(1), dim3(64), 0, s, ctl, v0, v1, v2, v3, v4);
+    return hipGetLastError();
+}
+
 template <int G, int NQR, int WPE, bool SPEC>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = SPEC ? 1 : 64 / G;
@@ -868,7 +886,13 @@ hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, fl
 
 hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xpos, const float *xquat, int T,
                             float *contrib, float *partial, hipStream_t s) {
-    hipLaunchKernelGGL(m_contrib_kernel, dim3((T + 63) / 64), dim3(64), 0, s, M, kp, xpos, xquat, T, contrib);
+    // T == 0 (a rank of a sharded fit that owns no sampled frame): no contributions, the sums below come out as
+    // zeros with partial[3K+1] = 0 -- a zero-block grid would be an invalid launch
+    if (T > 0) {
+        hipLaunchKernelGGL(m_contrib_kernel, dim3((T + 63) / 64), dim3(64), 0, s, M, kp, xpos, xquat, T, contrib);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const int W = 3 * M.K + 2;
     hipLaunchKernelGGL(m_reduce_kernel, dim3((W + 127) / 128), dim3(128), 0, s, contrib, T, M.K, partial);
     return hipGetLastError();

@@ -125,6 +125,7 @@ struct QArgs {
     const uint8_t *kpw;     // device [K] bytes: trunk mask (weights of the root passes)
     const uint8_t *kpw3;    // device [3K] per-coordinate mask for single-solve mode (or null)
     const uint8_t *kpw_sorted;  // device [K] trunk mask by sorted-site position (LM solver)
+    const float *bounds;    // device [2 * nqpad] lb then ub overriding the plan's for this call (stac_q_solve), or null
     int32_t C, F, P;
     int32_t root_kp_idx, do_root_opt;
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)

@@ -1,7 +1,8 @@
 """Multi-GPU plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL on ROCm).
 
 The q_phase shards by clips (independent warm-start chains): contiguous blocks of
-clips per rank, no data-path collective; results are gathered to every rank for packaging.  The
+clips per rank, no data-path collective; results are gathered to rank 0 for packaging (or stay as
+per-rank shards; a 1 M-frame run is 2.7 GB of outputs, which no other rank needs).  The
 offset phase has one real exchange step: the per-rank partial sums ``[s(3K), z2, T]`` are combined
 with ONE all-reduce of 3K+2 floats (``stac_core.py:157-160`` summed over ranks).  For run-to-run
 determinism ``deterministic=True`` uses all-gather + fixed-order sum instead of a ring reduce.
@@ -73,4 +74,21 @@ def all_gather_clips(local: torch.Tensor, n_total: int) -> torch.Tensor:
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(w)]
     tdist.all_gather(bufs, pad)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def gather_clips(local: torch.Tensor, n_total: int, dst: int = 0):
+    """Per-rank clip blocks (dim 0) concatenated in rank order on rank ``dst`` only; other ranks get None.
+    Ragged shards are padded to the largest one for the collective."""
+    if not is_dist():
+        return local
+    w, r = tdist.get_world_size(), tdist.get_rank()
+    sizes = [shard_range(n_total, k, w) for k in range(w)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(w)] if r == dst else None
+    tdist.gather(pad, bufs, dst=dst)
+    if r != dst:
+        return None
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

@@ -74,7 +74,7 @@ def load_library(path: Path | None = None):
     lib.stac_set_site_pos.argtypes = [vp, vp, vp]
     lib.stac_get_site_pos.argtypes = [vp, vp, vp]
     lib.stac_fk.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp, vp]
-    lib.stac_q_solve.argtypes = [vp, C.POINTER(StacQParams), vp, vp, _u8p, _u8p, C.c_int32, vp, vp, vp, vp]
+    lib.stac_q_solve.argtypes = [vp, C.POINTER(StacQParams), vp, vp, _u8p, _u8p, _f32p, _f32p, C.c_int32, vp, vp, vp, vp]
     lib.stac_q_phase.argtypes = [vp, C.POINTER(StacQParams), vp, vp, _u8p, _u8p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.stac_m_phase_partial.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
@@ -106,6 +106,8 @@ class Engine:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         torch.cuda.set_device(self.device)
         self.nq, self.nbody, self.njnt, self.K = tables.nq, tables.nbody, tables.njnt, tables.nsite
+        self.lb = np.ascontiguousarray(lb, dtype=np.float32).copy()
+        self.ub = np.ascontiguousarray(ub, dtype=np.float32).copy()
         self.params = StacQParams(float(tol), int(maxiter), int(maxls), int(lanes_per_chain), SOLVERS["pg"], 0.0)
         # q_phase may use the optional LM solver; q_solve (the StacCore.q_opt seam) always runs the reference's PG
         self.phase_params = StacQParams(float(tol), int(lm_maxiter if solver == "lm" else maxiter), int(maxls),
@@ -167,8 +169,9 @@ class Engine:
     # -- offsets ------------------------------------------------------------------------------
     def set_site_pos(self, offsets):
         off = self._dev(offsets).reshape(self.K, 3)
+        # `off` may be a temporary: its block returns to torch's caching allocator, which hands it out again only to
+        # work queued behind this call on the same stream -- no host synchronisation needed
         self._check(self.lib.stac_set_site_pos(self._h, _ptr(off), self._stream()))
-        torch.cuda.current_stream(self.device).synchronize()  # `off` may be a temporary
 
     def get_site_pos(self) -> torch.Tensor:
         out = torch.empty((self.K, 3), dtype=torch.float32, device=self.device)
@@ -190,8 +193,9 @@ class Engine:
                                      _ptr(out["site_xpos"]), self._stream()))
         return out
 
-    def q_solve(self, kp, q0, qs_to_opt, kps_to_opt):
-        """Batched ``StacCore.q_opt``: kp[N,3K], q0[N,nq] -> params[N,nq], state[N,4], counters[N,4]."""
+    def q_solve(self, kp, q0, qs_to_opt, kps_to_opt, lb=None, ub=None):
+        """Batched ``StacCore.q_opt``: kp[N,3K], q0[N,nq] -> params[N,nq], state[N,4], counters[N,4].
+        ``lb`` / ``ub`` (host, [nq]) give the box of this call; None = the bounds the engine was built with."""
         kp = self._dev(kp).reshape(-1, 3 * self.K)
         q0 = self._dev(q0).reshape(-1, self.nq)
         N = kp.shape[0]
@@ -200,9 +204,18 @@ class Engine:
         params = torch.empty((N, self.nq), dtype=torch.float32, device=self.device)
         state = torch.empty((N, 4), dtype=torch.float32, device=self.device)
         counters = torch.empty((N, 4), dtype=torch.int32, device=self.device)
+        if (lb is None) != (ub is None):
+            raise ValueError("lb and ub must be given together")
+        lbp = ubp = None
+        if lb is not None:
+            lb_h = np.ascontiguousarray(np.asarray(lb, dtype=np.float32).reshape(-1))
+            ub_h = np.ascontiguousarray(np.asarray(ub, dtype=np.float32).reshape(-1))
+            if lb_h.size != self.nq or ub_h.size != self.nq:
+                raise ValueError(f"lb / ub must have {self.nq} entries")
+            lbp, ubp = lb_h.ctypes.data_as(_f32p), ub_h.ctypes.data_as(_f32p)
         self._check(self.lib.stac_q_solve(self._h, C.byref(self.params), _ptr(kp), _ptr(q0), qs.ctypes.data_as(_u8p),
-                                          ks.ctypes.data_as(_u8p), N, _ptr(params), _ptr(state), _ptr(counters),
-                                          self._stream()))
+                                          ks.ctypes.data_as(_u8p), lbp, ubp, N, _ptr(params), _ptr(state),
+                                          _ptr(counters), self._stream()))
         return params, state, counters
 
     def q_phase(self, kp, *, part_masks, trunk_kps=None, root_kp_idx=-1, root_dims=7, do_root_opt=False, q_init=None,
@@ -244,8 +257,8 @@ class Engine:
         ws_n = int(self.lib.stac_m_phase_workspace_floats(self._h, T))
         ws = torch.empty(max(ws_n, 1), dtype=torch.float32, device=self.device)
         partial = torch.empty(3 * self.K + 2, dtype=torch.float32, device=self.device)
+        # the workspace is a temporary of torch's stream-ordered caching allocator (see set_site_pos): no host sync
         self._check(self.lib.stac_m_phase_partial(self._h, _ptr(kp), _ptr(q), T, _ptr(ws), _ptr(partial), self._stream()))
-        torch.cuda.current_stream(self.device).synchronize()  # workspace is a temporary
         return partial
 
     def m_finish(self, partial, initial_offsets, is_regularized, reg_coef):
@@ -256,7 +269,6 @@ class Engine:
         err = torch.empty(1, dtype=torch.float32, device=self.device)
         self._check(self.lib.stac_m_phase_finish(self._h, _ptr(partial), _ptr(m0), _ptr(d), C.c_float(float(reg_coef)),
                                                  _ptr(out), _ptr(err), self._stream()))
-        torch.cuda.current_stream(self.device).synchronize()
         return out, err
 
     def m_opt(self, kp, q, initial_offsets, is_regularized, reg_coef):

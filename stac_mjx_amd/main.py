@@ -44,7 +44,7 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
         kps = kp_data[: cfg.stac.n_fit_frames]
         print(f"Running fit. Mocap data shape: {kps.shape}")
         fit_data = stac.fit_offsets(kps)
-        if dist.world()[0] == 0:  # multi-GPU: every rank holds the same result, rank 0 writes it
+        if dist.world()[0] == 0:  # multi-GPU: rank 0 holds the gathered result and writes it
             io.save_data_to_h5(config=cfg, file_path=fit_offsets_path, **fit_data.as_dict())
         fit_offsets_path = io.resolve_output_path(fit_offsets_path)
         dist.barrier()
@@ -60,8 +60,14 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
             f"n_frames_per_clip ({cfg.stac.n_frames_per_clip}) must divide evenly with the total number of mocap "
             f"frames({kp_data.shape[0]})")
     print("Running ik_only()")
-    _, fit_data = io.load_stac_data(fit_offsets_path)
+    # the config stored with the fit replaces the caller's from here on, as in the reference (main.py:111): it decides
+    # continuous / n_frames_per_clip / infer_qvels below and is what the ik_only file records (the Stac object
+    # itself keeps the caller's config, also as in the reference)
+    cfg, fit_data = io.load_stac_data(fit_offsets_path)
     ik_data = stac.ik_only(kp_data, fit_data.offsets)
+    if dist.world()[0] != 0 and str(stac.cfg.stac.get("gather", "rank0") or "rank0") != "all":
+        dist.barrier()  # this rank holds its own shard only: rank 0 post-processes and writes the gathered result
+        return fit_offsets_path, io.resolve_output_path(ik_only_path)
     if cfg.stac.continuous:
         ik_data = utils.handle_edge_effects(ik_data, cfg.stac.n_frames_per_clip)
     print(f"Final qpos shape: {ik_data.qpos.shape}")

@@ -131,8 +131,8 @@ class Stac:
             eng.set_site_pos(new_off)
             self._offsets = new_off
         if fpc > 0 and dist.is_dist():
-            res = {k: (dist.all_gather_clips(v, n_clips) if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
-        return self._package_data(res, kp_np.reshape(n, -1), batched=fpc > 0)
+            res, kp_np = self._gather(res, kp_np, n_clips, lo, hi)
+        return self._package_data(res, kp_np.reshape(kp_np.shape[0] * n_per, -1), batched=fpc > 0)
 
     # -- ik_only (stac.py:356-454) --------------------------------------------------------------------------
     def ik_only(self, kp_data, offsets) -> StacData:
@@ -148,21 +148,45 @@ class Stac:
             self._log("Missing or invalid ROOT_OPTIMIZATION_KEYPOINT, skipping root_optimization()")
         res = self._q_phase(kp, do_root_opt=self.setup.do_root_opt)
         if dist.is_dist():
-            res = {k: (dist.all_gather_clips(v, n_clips) if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
+            res, batched = self._gather(res, batched, n_clips, lo, hi)
         _, mean, std = self._get_error_stats(res["frame_error"].cpu().numpy())
         self._log(f"Mean: {mean}\nStandard deviation: {std}")
         self._offsets = eng.get_site_pos()
         return self._package_data(res, batched, batched=True)
 
+    def _gather(self, res, kp_clips, n_clips, lo, hi):
+        """Multi-GPU result placement, ``stac.gather`` (engine extension): "rank0" (default) -- rank 0 packages every
+        clip, the other ranks keep (and return) their own shard; "all" -- every rank gets every clip (small runs,
+        tests); "none" -- every rank keeps its shard.  Returns (results, the keypoint clips that go with them)."""
+        mode = str(self.cfg.stac.get("gather", "rank0") or "rank0")
+        if mode not in ("rank0", "all", "none"):
+            raise ValueError(f"stac.gather must be rank0, all or none, not {mode!r}")
+        tensors = {k: v for k, v in res.items() if isinstance(v, torch.Tensor)}
+        if mode == "all":
+            return {k: dist.all_gather_clips(v, n_clips) for k, v in tensors.items()}, kp_clips
+        if mode == "rank0":
+            full = {k: dist.gather_clips(v, n_clips, dst=0) for k, v in tensors.items()}
+            if dist.world()[0] == 0:
+                return full, kp_clips
+        return tensors, kp_clips[lo:hi]
+
     # -- packing (stac.py:456-503) ---------------------------------------------------------------------------
     def _package_data(self, res, kp_data, batched=False) -> StacData:
-        """Clip-major flatten of every field.  (The reference flattens ``marker_sites`` frame-major when
-        C > 1 and F > 1 -- SURVEY.md A5-7, a reference bug; here all fields share the clip-major order.)"""
+        """Clip-major flatten of every field.
+
+        The reference flattens ``marker_sites`` frame-major when C > 1 and F > 1 (``stac.py:486``: a C-order
+        reshape of the (F, C, K, 3) stack, while qpos / xpos / xquat / kp_data come out clip-major -- SURVEY.md
+        A5-7, a reference bug).  Default here: all fields clip-major, row i of every field is the same frame.
+        ``stac.reference_marker_order: true`` reproduces the reference's row order of ``marker_sites`` exactly
+        (row j = frame j // C of clip j % C) for consumers that undo it themselves."""
         nq, nb, K = self.setup.tables.nq, self.setup.tables.nbody, self.setup.tables.nsite
         qpos = res["qpos"].reshape(-1, nq).cpu().numpy()
         xpos = res["xpos"].reshape(-1, nb, 3).cpu().numpy()
         xquat = res["xquat"].reshape(-1, nb, 4).cpu().numpy()
-        markers = res["marker_sites"].reshape(-1, K, 3).cpu().numpy()
+        ms = res["marker_sites"]
+        if batched and ms.dim() == 4 and bool(self.cfg.stac.get("reference_marker_order", False)):
+            ms = ms.transpose(0, 1)  # (C, F, K, 3) -> (F, C, K, 3), flattened in C order like stac.py:486
+        markers = ms.reshape(-1, K, 3).cpu().numpy()
         offsets = np.asarray(torch.as_tensor(self._offsets).cpu()).reshape(K, 3)
         kp_flat = np.asarray(kp_data).reshape(-1, np.asarray(kp_data).shape[-1])
         return StacData(qpos=qpos, xpos=xpos, xquat=xquat, marker_sites=markers, offsets=offsets,

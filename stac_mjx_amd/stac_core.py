@@ -70,20 +70,35 @@ class DataHandle:
 class StacCore:
     """Pose (projected gradient) and offset (closed form) optimisation on the GPU engine."""
 
-    def __init__(self, engine, tol: float = 1e-5, n_iter_q: int = 400):
+    def __init__(self, engine, tol: float = 1e-5, n_iter_q: int = 400, site_idxs=None):
         self.engine = engine
+        # model site ids of the engine's K fit sites (stac.py:227-235), when the caller knows them
+        self.site_idxs = None if site_idxs is None else np.asarray(site_idxs).reshape(-1)
         self.tol = float(tol)
         self.n_iter_q = int(n_iter_q)
         engine.params.tol = self.tol
         engine.params.maxiter = self.n_iter_q
 
     def q_opt(self, mjx_model, mjx_data, marker_ref_arr, qs_to_opt, kps_to_opt, q0, lb=None, ub=None, site_idxs=None):
-        """One ``StacCore.q_opt`` (``stac_core.py:193-235``).  ``lb/ub/site_idxs`` are fixed at engine
-        construction and accepted here only for signature compatibility."""
+        """One ``StacCore.q_opt`` (``stac_core.py:193-235``).  ``lb`` / ``ub`` are the box of THIS call, as in the
+        reference (``hyperparams_proj``); None = the bounds the engine was built with.  ``site_idxs`` is fixed at
+        engine construction (the engine's K fit sites ARE ``site_idxs``): passing a different index set raises."""
         e = self.engine
         qs = np.asarray(torch.as_tensor(qs_to_opt).cpu()).astype(bool)
         ks = np.asarray(torch.as_tensor(kps_to_opt).cpu()).astype(bool)
-        params, state, counters = e.q_solve(torch.as_tensor(marker_ref_arr).reshape(1, -1), torch.as_tensor(q0).reshape(1, -1), qs, ks)
+        if (lb is None) != (ub is None):
+            raise ValueError("lb and ub must be given together")
+        if lb is not None:
+            lb = np.asarray(torch.as_tensor(lb).cpu(), dtype=np.float32).reshape(-1)
+            ub = np.asarray(torch.as_tensor(ub).cpu(), dtype=np.float32).reshape(-1)
+            if np.array_equal(lb, e.lb) and np.array_equal(ub, e.ub):
+                lb = ub = None  # the engine's own box: nothing to upload
+        if site_idxs is not None:
+            si = np.asarray(torch.as_tensor(site_idxs).cpu()).reshape(-1)
+            if si.size != e.K or (self.site_idxs is not None and not np.array_equal(si, self.site_idxs)):
+                raise ValueError("site_idxs differs from the fit sites this engine was built with")
+        params, state, counters = e.q_solve(torch.as_tensor(marker_ref_arr).reshape(1, -1), torch.as_tensor(q0).reshape(1, -1), qs, ks,
+                                            lb=lb, ub=ub)
         s = state[0].cpu().numpy()
         c = counters[0].cpu().numpy()
         st = PGState(iter_num=int(c[0]), stepsize=float(s[1]), error=float(s[0]), t=float(s[2]), loss=float(s[3]),

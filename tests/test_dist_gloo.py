@@ -41,6 +41,15 @@ def _worker(rank, world, port, q):
         local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
         full = dist.all_gather_clips(local, n_total)
         assert torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float32))
+        # rank-0 gather (what Stac uses by default): rank 0 gets every clip in order, the others nothing
+        g0 = dist.gather_clips(local, n_total, dst=0)
+        assert (g0 is None) if rank else torch.equal(g0, full)
+        # more ranks than clips: the last rank owns nothing, the collectives still line up
+        lo1, hi1 = dist.shard_range(1)
+        one = torch.full((hi1 - lo1, 2), 7.0)
+        g1 = dist.gather_clips(one, 1, dst=0)
+        assert (g1 is None) if rank else (g1.shape == (1, 2) and float(g1[0, 0]) == 7.0)
+        assert dist.all_gather_clips(one, 1).shape == (1, 2)
         # offset phase: per-rank partial sums -> one all-reduce -> same closed form on every rank
         t = ModelTables.load(GOLDEN / "rodent_tables_legacy.npz")
         with np.load(GOLDEN / "demo_viz_golden.npz") as d:

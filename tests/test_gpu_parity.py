@@ -652,3 +652,50 @@ def test_random_models_bit_exact(seed):
             np.testing.assert_array_equal(_np(fk["site_xpos"][i]), o["site_xpos"])
         res = eng.q_phase(kp, part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=do_root)
         _compare_phase(res, ref)
+
+
+# ---- boundary details ---------------------------------------------------------------------------------------------------
+def test_q_solve_per_call_bounds(rodent_setup, rodent_mocap):
+    """StacCore.q_opt takes lb / ub per call (stac_core.py:193-235, hyperparams_proj): a box passed to stac_q_solve
+    overrides the model's for that call only, equals the oracle with the same box, and the next call without a box
+    is back on the model's bounds."""
+    fs = rodent_setup
+    eng, orc = _engine(fs, maxiter=50), _oracle(fs, maxiter=50)
+    kp, q0 = rodent_mocap[20:26], np.tile(fs.tables.qpos0, (6, 1))
+    q0[:, :3] = kp[:, 3 * fs.root_kp_idx : 3 * fs.root_kp_idx + 3]
+    ones_q, ones_k = np.ones(74, np.uint8), np.ones(69, np.uint8)
+    lb2, ub2 = np.maximum(fs.lb, -0.05).astype(np.float32), np.minimum(fs.ub, 0.05).astype(np.float32)
+    lb2[:7], ub2[:7] = fs.lb[:7], fs.ub[:7]
+    base, _, _ = eng.q_solve(kp, q0, ones_q, ones_k)
+    tight, st, cnt = eng.q_solve(kp, q0, ones_q, ones_k, lb=lb2, ub=ub2)
+    again, _, _ = eng.q_solve(kp, q0, ones_q, ones_k)
+    assert (base == again).all() and not (base == tight).all()
+    tight = _np(tight)
+    assert (tight[:, 7:] >= -0.05).all() and (tight[:, 7:] <= 0.05).all()
+    for i in range(6):
+        ref, rst = orc.q_opt(kp[i], ones_q, ones_k, q0[i], lb2, ub2)
+        np.testing.assert_array_equal(tight[i], ref)
+        assert int(_np(cnt)[i, 0]) == rst["iter_num"] and float(_np(st)[i, 0]) == np.float32(rst["error"])
+        ref0, _ = orc.q_opt(kp[i], ones_q, ones_k, q0[i], fs.lb, fs.ub)
+        np.testing.assert_array_equal(_np(base)[i], ref0)
+    from stac_mjx_amd.engine import StacHipError
+
+    with pytest.raises(StacHipError, match="lb > ub"):
+        eng.q_solve(kp, q0, ones_q, ones_k, lb=ub2 + 1.0, ub=ub2)
+
+
+def test_m_partial_with_zero_frames(rodent_setup):
+    """T = 0 (a rank of a sharded fit without sampled frames): zero sums, T = 0, no invalid launch; the closed form on
+    it keeps unregularised offsets where they were instead of dividing 0 by 0."""
+    fs = rodent_setup
+    eng, orc = _engine(fs), _oracle(fs)
+    part = _np(eng.m_partial(np.zeros((0, 69), np.float32), np.zeros((0, 74), np.float32)))
+    np.testing.assert_array_equal(part, np.zeros(71, np.float32))
+    m0 = fs.tables.site_pos
+    d = np.zeros((23, 3), np.float32)
+    d[:5] = 1.0
+    out, err = eng.m_finish(part, m0, d, 1.0)
+    ref, rerr = orc.m_finish(part, m0, d, 1.0)
+    np.testing.assert_array_equal(_np(out), ref)
+    np.testing.assert_array_equal(_np(out), m0)
+    assert float(err[0]) == rerr == 0.0

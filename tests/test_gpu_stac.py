@@ -172,7 +172,7 @@ def test_fit_offsets_clip_parallel_extension(rodent_setup, rodent_cfg, rodent_mo
     np.testing.assert_array_equal(data.marker_sites, ref["marker_sites"].reshape(12, 23, 3))
 
 
-def _two_rank_fit(rank, port, tmp, kp, fpc):
+def _two_rank_fit(rank, port, tmp, kp, fpc, tix, gather):
     import os
 
     import torch.distributed as dist
@@ -189,31 +189,105 @@ def _two_rank_fit(rank, port, tmp, kp, fpc):
 
         mcfg = json.load(open(G / "rodent_model_cfg.json"))
         fs = finish_fit_setup(ModelTables.load(G / "rodent_tables.npz"), mcfg, list(mcfg["KEYPOINT_MODEL_PAIRS"].keys()))
-        cfg = _cfg(mcfg, fit_frames_per_clip=fpc)
+        cfg = _cfg(mcfg, fit_frames_per_clip=fpc, gather=gather)
         cfg.model.N_ITERS = 2
-        data = Stac(None, cfg, fs.kp_names, setup=fs, verbose=False).fit_offsets(kp)
-        np.savez(f"{tmp}/rank{rank}.npz", offsets=data.offsets, qpos=data.qpos, markers=data.marker_sites)
+        data = Stac(None, cfg, fs.kp_names, setup=fs, verbose=False).fit_offsets(kp, time_indices=tix)
+        np.savez(f"{tmp}/rank{rank}.npz", offsets=data.offsets, qpos=data.qpos, markers=data.marker_sites, kp=data.kp_data)
     finally:
         dist.destroy_process_group()
 
 
-def test_fit_offsets_clip_parallel_two_ranks_on_one_gpu(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
-    """The sharded calibration with a real process group (2 ranks sharing cuda:0, gloo): clips split 3 + 2, the
-    3K+2 partial sums all-reduced in fixed rank order; both ranks end with the same offsets and the gathered poses,
-    and they agree with the single-process run (the offset sums associate differently: 1e-6)."""
+def _spawn_two(tmp_path, kp, fpc, tix=None, gather="rank0"):
     import torch.multiprocessing as mp
 
+    port = 29600 + (int(torch.randint(0, 300, (1,)).item()))
+    mp.spawn(_two_rank_fit, args=(port, str(tmp_path), kp, fpc, tix, gather), nprocs=2, join=True)
+    return np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+
+
+def test_fit_offsets_clip_parallel_two_ranks_on_one_gpu(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
+    """The sharded calibration with a real process group (2 ranks sharing cuda:0, gloo): clips split 3 + 2, the
+    3K+2 partial sums all-reduced in fixed rank order; both ranks end with the same offsets; rank 0 packages every
+    clip, rank 1 keeps its shard (stac.gather = rank0, the default); "all" replicates.  The result agrees with the
+    single-process run (the offset sums associate differently: 1e-6)."""
     from stac_mjx_amd.stac import Stac
 
     kp = rodent_mocap[300:310]  # 5 clips of 2
     cfg = _cfg(rodent_cfg, fit_frames_per_clip=2)
     cfg.model.N_ITERS = 2
     one = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False).fit_offsets(kp)
-    port = 29600 + (int(torch.randint(0, 300, (1,)).item()))
-    mp.spawn(_two_rank_fit, args=(port, str(tmp_path), kp, 2), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in ("offsets", "qpos", "markers"):
-        np.testing.assert_array_equal(r0[k], r1[k])
-    assert r0["qpos"].shape == (10, 74)
+    r0, r1 = _spawn_two(tmp_path, kp, 2)
+    np.testing.assert_array_equal(r0["offsets"], r1["offsets"])
+    assert r0["qpos"].shape == (10, 74) and r1["qpos"].shape == (4, 74)
+    for k in ("qpos", "markers", "kp"):
+        np.testing.assert_array_equal(r0[k][6:], r1[k])  # rank 1 owns clips 3-4 = frames 6-9
+    np.testing.assert_array_equal(r0["kp"], kp)
     assert np.abs(r0["offsets"] - one.offsets).max() < 1e-5
     assert np.abs(r0["markers"] - one.marker_sites).max() < 1e-3
+    a0, a1 = _spawn_two(tmp_path, kp, 2, gather="all")
+    for k in ("offsets", "qpos", "markers"):
+        np.testing.assert_array_equal(a0[k], a1[k])
+        np.testing.assert_array_equal(a0[k], r0[k])
+
+
+def test_fit_offsets_sharded_rank_without_sampled_frames_or_clips(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
+    """A rank whose shard holds no sampled frame runs the offset phase with T = 0 (zero partial sums, no kernel with
+    an empty grid) and a rank that owns no clip at all launches nothing: the job neither hangs nor diverges."""
+    from stac_mjx_amd.stac import Stac
+
+    kp = rodent_mocap[300:310]
+    tix = np.array([0, 1, 2, 3, 5])  # every sampled frame lives on rank 0 (clips 0-2)
+    cfg = _cfg(rodent_cfg, fit_frames_per_clip=2)
+    cfg.model.N_ITERS = 2
+    one = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False).fit_offsets(kp, time_indices=tix)
+    r0, r1 = _spawn_two(tmp_path, kp, 2, tix=tix)
+    np.testing.assert_array_equal(r0["offsets"], r1["offsets"])
+    np.testing.assert_array_equal(r0["offsets"], one.offsets)  # rank 1 adds exact zeros: same bits as one process
+    np.testing.assert_array_equal(r0["qpos"], one.qpos)
+    # one clip, two ranks: rank 1 has nothing to do
+    s0, s1 = _spawn_two(tmp_path, kp[:2], 2)
+    one1 = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False).fit_offsets(kp[:2])
+    np.testing.assert_array_equal(s0["offsets"], one1.offsets)
+    np.testing.assert_array_equal(s0["offsets"], s1["offsets"])
+    np.testing.assert_array_equal(s0["qpos"], one1.qpos)
+    assert s1["qpos"].shape == (0, 74)
+
+
+def test_ik_only_continuous_clips_and_edge_effects(rodent_setup, rodent_cfg, rodent_mocap):
+    """stac.continuous: windows of n_frames_per_clip + 10 frames (the last one wrap-padded, utils.py:369-382) run as
+    independent chains, then the overlaps are cross-faded (utils.py:393-461).  HIP == oracle on every window; the
+    stitched result equals an independent statement of the cross-fade applied to the oracle's windows."""
+    from oracle import Oracle
+    from stac_mjx_amd import utils
+    from stac_mjx_amd.stac import Stac
+
+    fs = rodent_setup
+    n, C, OV = 12, 3, utils.CONTINUOUS_BATCH_OVERLAP
+    kp = rodent_mocap[200 : 200 + n * C]
+    cfg = _cfg(rodent_cfg, n_frames_per_clip=n, continuous=True)
+    cfg.model.N_ITER_Q = 30
+    off = fs.tables.site_pos + 0.001
+    stac = Stac(None, cfg, fs.kp_names, setup=fs, verbose=False)
+    data = stac.ik_only(kp, off)
+    win = np.stack([kp[c * n : c * n + n + OV] for c in range(C - 1)] + [np.pad(kp[(C - 1) * n :], ((0, OV), (0, 0)), mode="wrap")])
+    orc = Oracle(fs.tables, tol=float(rodent_cfg["FTOL"]), maxiter=30)
+    orc.set_site_pos(off)
+    ref = orc.ik_clips(win, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    assert data.qpos.shape == (C * (n + OV), 74)
+    np.testing.assert_array_equal(data.qpos, ref["qpos"].reshape(-1, 74))
+    np.testing.assert_array_equal(data.marker_sites, ref["marker_sites"].reshape(-1, 23, 3))
+    np.testing.assert_array_equal(data.xquat, ref["xquat"].reshape(-1, 67, 4))
+    np.testing.assert_array_equal(data.kp_data, win.reshape(-1, 69))
+    out = utils.handle_edge_effects(data, n)
+    m = 1.0 / (1.0 + np.exp(-10.0 * (np.linspace(0.0, 1.0, OV) - 0.5)))
+    for name, r in (("qpos", ref["qpos"]), ("marker_sites", ref["marker_sites"]), ("xpos", ref["xpos"]), ("kp_data", win)):
+        o = getattr(out, name)
+        assert o.shape[0] == n * C
+        for c in range(C):
+            for f in range(n):
+                want = r[c, f].astype(np.float64)
+                if c > 0 and f < OV:
+                    want = (1.0 - m[f]) * r[c - 1, n + f] + m[f] * r[c, f]
+                np.testing.assert_allclose(o[c * n + f], want, rtol=1e-6, atol=1e-7)
+    # the stitched keypoints are the input again wherever both windows saw the same frames (the fade of equal values)
+    np.testing.assert_allclose(out.kp_data, kp, rtol=1e-6, atol=1e-7)

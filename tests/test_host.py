@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = load_library()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.stac_abi_version() == 2
+    assert lib.stac_abi_version() == 3
     assert lib.stac_device_count() >= 0
 
 
@@ -316,3 +316,170 @@ def test_quat_helpers_and_velocity():
     assert v.shape == (T, 7)
     assert np.allclose(v[:-1, 0], 3.0) and np.allclose(v[:-1, 3:6], [0, 0, w], atol=1e-6)
     assert np.allclose(v[:-1, 6], 20.0) and np.allclose(v[-1], 0.0)
+
+
+# ---- continuous clips: wrap padding and the cross-fade, numerically (stac_mjx/utils.py:350-461) -----------------------
+@pytest.mark.parametrize("n_per,n_clips", [(20, 3), (10, 2), (12, 4), (250, 2)])
+def test_batch_kp_data_continuous_equals_pad_wrap(n_per, n_clips):
+    """The windows are kp[s : s + n + 10] and the LAST one is `jp.pad(..., ((0, 10), (0, 0)), mode="wrap")`
+    (utils.py:369-382; numpy's pad has the same wrap semantics): checked row by row.  Clips shorter than the
+    overlap leave the second-to-last window short, which the reference's `jp.stack` rejects: ValueError here too."""
+    from stac_mjx_amd.utils import CONTINUOUS_BATCH_OVERLAP as OV
+    from stac_mjx_amd.utils import batch_kp_data
+
+    rng = np.random.default_rng(n_per * 100 + n_clips)
+    kp = rng.normal(size=(n_per * n_clips, 6)).astype(np.float32)
+    out = batch_kp_data(kp, n_per, continuous=True)
+    assert out.shape == (n_clips, n_per + OV, 6)
+    for c in range(n_clips - 1):
+        np.testing.assert_array_equal(out[c], kp[c * n_per : c * n_per + n_per + OV])
+    last = kp[(n_clips - 1) * n_per :]
+    np.testing.assert_array_equal(out[-1], np.pad(last, ((0, OV), (0, 0)), mode="wrap"))
+    tk = batch_kp_data(torch.as_tensor(kp), n_per, continuous=True)  # the torch branch does the same
+    np.testing.assert_array_equal(tk.numpy(), out)
+    with pytest.raises((ValueError, RuntimeError)):
+        batch_kp_data(kp[: 4 * 5], 4, continuous=True)
+
+
+def test_handle_edge_effects_numeric():
+    """Frame t of the output is clip t // n's own result, except the first 10 frames of every clip after the first:
+    those are the sigmoid cross-fade (1 - m) * [tail of the previous window] + m * [head of this window] with
+    m = sigmoid(10 * (linspace(0, 1, 10) - 0.5)) (utils.py:393-461)."""
+    from stac_mjx_amd.utils import CONTINUOUS_BATCH_OVERLAP as OV
+    from stac_mjx_amd.utils import handle_edge_effects
+
+    n, C = 25, 4
+    rng = np.random.default_rng(3)
+    fields = {k: rng.normal(size=(C, n + OV) + s) for k, s in
+              dict(qpos=(7,), kp_data=(6,), xpos=(5, 3), xquat=(5, 4), marker_sites=(2, 3)).items()}
+    data = types.SimpleNamespace(**{k: v.reshape((-1,) + v.shape[2:]).copy() for k, v in fields.items()})
+    out = handle_edge_effects(data, n)
+    m = 1.0 / (1.0 + np.exp(-10.0 * (np.linspace(0.0, 1.0, OV) - 0.5)))
+    for k, v in fields.items():
+        o = getattr(out, k)
+        assert o.shape == (C * n,) + v.shape[2:]
+        for c in range(C):
+            for f in range(n):
+                want = v[c, f]
+                if c > 0 and f < OV:
+                    mm = m[f]
+                    want = (1.0 - mm) * v[c - 1, n + f] + mm * v[c, f]
+                np.testing.assert_allclose(o[c * n + f], want, rtol=1e-12, atol=1e-12)
+
+
+# ---- packing order, per-call bounds, config rebinding -------------------------------------------------------------------
+def _bare_stac(rodent_setup, rodent_cfg, **stac_over):
+    """A Stac object without an engine (no GPU): enough for the host-side packing logic."""
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.stac import Stac
+
+    stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=4,
+                skip_fit_offsets=False, skip_ik_only=False, infer_qvels=False, n_frames_per_clip=3,
+                mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+    stac.update(stac_over)
+    s = Stac.__new__(Stac)
+    s.cfg = validate_config({"model": dict(rodent_cfg), "stac": stac})
+    s.setup = rodent_setup
+    s._part_names, s._body_names, s._kp_names = rodent_setup.part_names, rodent_setup.tables.body_names, rodent_setup.kp_names
+    s._offsets = torch.zeros(23, 3)
+    return s
+
+
+def test_package_data_marker_order_default_and_reference_compat(rodent_setup, rodent_cfg):
+    """Default: every field clip-major.  `stac.reference_marker_order: true`: marker_sites in the reference's row
+    order, a C-order flatten of the (F, C, K, 3) stack (stac.py:486): row j = frame j // C of clip j % C."""
+    C, F = 4, 3
+    rng = np.random.default_rng(0)
+    res = dict(qpos=torch.as_tensor(rng.normal(size=(C, F, 74))), xpos=torch.zeros(C, F, 67, 3), xquat=torch.zeros(C, F, 67, 4),
+               marker_sites=torch.as_tensor(rng.normal(size=(C, F, 23, 3))))
+    kp = rng.normal(size=(C, F, 69))
+    d0 = _bare_stac(rodent_setup, rodent_cfg)._package_data(res, kp, batched=True)
+    d1 = _bare_stac(rodent_setup, rodent_cfg, reference_marker_order=True)._package_data(res, kp, batched=True)
+    ms = res["marker_sites"].numpy()
+    for j in range(C * F):
+        np.testing.assert_array_equal(d0.marker_sites[j], ms[j // F, j % F])   # clip-major, like qpos
+        np.testing.assert_array_equal(d1.marker_sites[j], ms[j % C, j // C])   # the reference's frame-major rows
+        np.testing.assert_array_equal(d0.qpos[j], res["qpos"].numpy()[j // F, j % F])
+    np.testing.assert_array_equal(d1.qpos, d0.qpos)  # only marker_sites is affected (stac.py:483-486)
+    # the re-ordering map a consumer of the reference's files applies: rows (f * C + c) -> (c * F + f)
+    perm = np.array([(j % F) * C + j // F for j in range(C * F)])
+    np.testing.assert_array_equal(d1.marker_sites[perm], d0.marker_sites)
+    # unbatched results (fit_offsets' single chain) are not touched by the switch
+    res1 = {k: v[0] for k, v in res.items()}
+    np.testing.assert_array_equal(_bare_stac(rodent_setup, rodent_cfg, reference_marker_order=True)._package_data(res1, kp[0]).marker_sites, ms[0])
+
+
+def test_stac_core_q_opt_passes_per_call_bounds_and_checks_site_idxs(rodent_setup):
+    """StacCore.q_opt takes lb / ub per call like the reference (stac_core.py:193-235): the engine's own box goes
+    down as "no override", a different box is handed to stac_q_solve, a foreign site_idxs raises."""
+    from stac_mjx_amd.stac_core import StacCore
+
+    fs = rodent_setup
+    calls = []
+
+    class FakeEngine:
+        K, nq = 23, 74
+        lb, ub = fs.lb.copy(), fs.ub.copy()
+        params = types.SimpleNamespace(tol=0.0, maxiter=0)
+
+        def q_solve(self, kp, q0, qs, ks, lb=None, ub=None):
+            calls.append((lb, ub))
+            return torch.zeros(1, 74), torch.zeros(1, 4), torch.zeros(1, 4, dtype=torch.int32)
+
+    core = StacCore(FakeEngine(), 1e-4, 400, site_idxs=np.arange(21, 44))
+    args = (None, None, np.zeros(69, np.float32), np.ones(74, bool), np.ones(69, bool), np.zeros(74, np.float32))
+    core.q_opt(*args)
+    core.q_opt(*args, torch.as_tensor(fs.lb), torch.as_tensor(fs.ub), np.arange(21, 44))
+    tight = np.maximum(fs.lb, -0.1)
+    core.q_opt(*args, tight, fs.ub)
+    assert calls[0] == (None, None) and calls[1] == (None, None)
+    np.testing.assert_array_equal(calls[2][0], tight)
+    with pytest.raises(ValueError, match="site_idxs"):
+        core.q_opt(*args, None, None, np.arange(20, 43))
+    with pytest.raises(ValueError, match="together"):
+        core.q_opt(*args, tight, None)
+
+
+def test_run_stac_rebinds_the_config_stored_with_the_fit(tmp_path, rodent_setup, rodent_cfg, monkeypatch):
+    """main.py:111: `cfg, fit_offsets_data = io.load_stac_data(fit_offsets_path)` -- with skip_fit_offsets the fit
+    file's config decides continuous / n_frames_per_clip / infer_qvels of the post-processing and is what the ik_only
+    file records, while the Stac object keeps the caller's config."""
+    from stac_mjx_amd import io, main
+    from stac_mjx_amd.config import validate_config
+
+    def mk(**over):
+        stac = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=4,
+                    skip_fit_offsets=True, skip_ik_only=False, infer_qvels=False, n_frames_per_clip=4,
+                    mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+        stac.update(over)
+        return validate_config({"model": dict(rodent_cfg), "stac": stac})
+
+    fit_cfg, caller_cfg = mk(infer_qvels=True, n_frames_per_clip=2), mk()
+    z = lambda *s: np.zeros(s, np.float32)
+    names = dict(kp_names=rodent_setup.kp_names, names_qpos=rodent_setup.part_names, names_xpos=rodent_setup.tables.body_names)
+    io.save_data_to_h5(config=fit_cfg, file_path=tmp_path / "fit.h5", kp_data=z(4, 69), marker_sites=z(4, 23, 3),
+                       offsets=np.full((23, 3), 0.5, np.float32), qpos=z(4, 74), xpos=z(4, 67, 3), xquat=z(4, 67, 4),
+                       qvel=np.array([]), **names)
+    seen = {}
+
+    class DummyStac:
+        _timestep, _freejoint = 0.002, True
+
+        def __init__(self, xml, cfg, kp_names, **kw):
+            self.cfg = cfg
+            seen["stac"] = self
+
+        def ik_only(self, kp, offsets):
+            seen["offsets"] = np.asarray(offsets)
+            q = z(8, 74)
+            q[:, 3] = 1.0
+            return io.StacData(qpos=q, xpos=z(8, 67, 3), xquat=z(8, 67, 4), marker_sites=z(8, 23, 3), offsets=np.asarray(offsets),
+                               kp_data=kp, **names)
+
+    monkeypatch.setattr(main, "Stac", DummyStac)
+    _, ik_path = main.run_stac(caller_cfg, z(8, 69), rodent_setup.kp_names, base_path=tmp_path)
+    saved_cfg, ik = io.load_stac_data(ik_path)
+    assert np.all(seen["offsets"] == 0.5)
+    assert seen["stac"].cfg is caller_cfg                       # the Stac object keeps the caller's config
+    assert saved_cfg.stac.infer_qvels is True and saved_cfg.stac.n_frames_per_clip == 2   # the file records the fit's
+    assert ik.qvel.shape == (8, 73)                             # and the fit's infer_qvels = True was applied
