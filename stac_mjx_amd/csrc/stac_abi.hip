@@ -992,10 +992,10 @@ extern "C" int32_t stac_q_solve(const stac_model *mc, const stac_q_params *p, co
                                 const uint8_t *qs_to_opt, const uint8_t *kps_to_opt, const float *lb, const float *ub,
                                 int32_t N, float *params_out, float *state_out, uint32_t *counters_out, void *stream) {
     stac_model *m = const_cast<stac_model *>(mc);
-    if (!m || !p || !kp || !q0 || !qs_to_opt || !kps_to_opt || !params_out || !state_out || N < 0)
-        return fail(STAC_ERR_INVALID, "stac_q_solve: bad argument");
+    if (!m || !p || !qs_to_opt || !kps_to_opt || N < 0) return fail(STAC_ERR_INVALID, "stac_q_solve: bad argument");
     if ((lb == nullptr) != (ub == nullptr)) return fail(STAC_ERR_INVALID, "stac_q_solve: lb and ub must be given together");
     if (N == 0) return STAC_OK;
+    if (!kp || !q0 || !params_out || !state_out) return fail(STAC_ERR_INVALID, "stac_q_solve: bad argument");
     if (p->solver != STAC_SOLVER_PG) return fail(STAC_ERR_INVALID, "stac_q_solve implements the reference's projected gradient only");
     DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
@@ -1039,13 +1039,13 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
                                 float *err_out, uint32_t *counters_out, float *q_carry_out, float *xpos_out,
                                 float *xquat_out, float *markers_out, void *stream) {
     stac_model *m = const_cast<stac_model *>(mc);
-    if (!m || !p || !kp || !qpos_out || !err_out || C < 0 || F < 0 || P < 0)
-        return fail(STAC_ERR_INVALID, "stac_q_phase: bad argument");
+    if (!m || !p || C < 0 || F < 0 || P < 0) return fail(STAC_ERR_INVALID, "stac_q_phase: bad argument");
+    if (C == 0 || F == 0) return STAC_OK;  // nothing to do (a rank of a sharded run that owns no clip): arrays may be empty
+    if (!kp || !qpos_out || !err_out) return fail(STAC_ERR_INVALID, "stac_q_phase: bad argument");
     if (P > 0 && !part_masks) return fail(STAC_ERR_INVALID, "stac_q_phase: part_masks is null");
     if (P + 3 > kMaxKinds) return fail(STAC_ERR_CAPACITY, "too many part groups");
     if (do_root_opt && (!trunk_kps || root_kp_idx < 0 || root_kp_idx >= m->h.K || root_dims < 1 || root_dims > m->h.nq))
         return fail(STAC_ERR_INVALID, "stac_q_phase: bad root optimisation arguments");
-    if (C == 0 || F == 0) return STAC_OK;
     DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
     const int nqpad = m->h.nqpad, K = m->h.K, nq = m->h.nq;
@@ -1101,7 +1101,8 @@ extern "C" int64_t stac_m_phase_workspace_floats(const stac_model *m, int32_t T)
 
 extern "C" int32_t stac_m_phase_partial(const stac_model *m, const float *kp, const float *q, int32_t T,
                                         float *workspace, float *partial, void *stream) {
-    if (!m || !kp || !q || !workspace || !partial || T < 0) return fail(STAC_ERR_INVALID, "stac_m_phase_partial: bad argument");
+    if (!m || !workspace || !partial || T < 0 || (T > 0 && (!kp || !q)))  // T = 0: kp / q may be empty (null) arrays
+        return fail(STAC_ERR_INVALID, "stac_m_phase_partial: bad argument");
     DeviceGuard dg(m);
     hipStream_t s = (hipStream_t)stream;
     const size_t nb = m->h.nbody;

@@ -59,6 +59,8 @@ class Stac:
 
     def _get_error_stats(self, errors):
         e = np.asarray(errors).reshape(-1)
+        if e.size == 0:  # a rank of a sharded run that owns no clip
+            return e, 0.0, 0.0
         return e, float(np.mean(e)), float(np.std(e))
 
     def _q_phase(self, kp, *, do_root_opt, q_init=None, want_outputs=True):
@@ -132,7 +134,7 @@ class Stac:
             self._offsets = new_off
         if fpc > 0 and dist.is_dist():
             res, kp_np = self._gather(res, kp_np, n_clips, lo, hi)
-        return self._package_data(res, kp_np.reshape(kp_np.shape[0] * n_per, -1), batched=fpc > 0)
+        return self._package_data(res, kp_np.reshape(kp_np.shape[0] * n_per, kp_np.shape[-1]), batched=fpc > 0)
 
     # -- ik_only (stac.py:356-454) --------------------------------------------------------------------------
     def ik_only(self, kp_data, offsets) -> StacData:
