@@ -424,28 +424,37 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.nqj = nqj;
     h.c_bx = o; o += (nst + 1) * 7;
     h.c_ja = o; o += naj * 7;
-    h.c_jn = o; o += naj;
+    h.c_jn = o; o += std::max(nqj, 1);
     h.c_qsv = o; o += 4 * nqj;
     o = (o + 3) & ~3;
     h.c_sw = o; o += std::max(K * 6, h.nqpad);
     o = (o + 3) & ~3;
     h.kpow2 = 1;
     while (h.kpow2 < K) h.kpow2 <<= 1;
-    h.c_gg = o; o += std::max(h.nqpad, K > 64 ? h.kpow2 : ((K + 3) & ~3));
-    o = (o + 3) & ~3;
+    // The gradient vector lives inside the body-transform array, behind the world entry and the root's (the joint pass
+    // reads the root position): the transforms are dead once the site pass is over.  Own region if it does not fit.
+    if ((nst + 1) * 7 - 14 >= h.nqpad) {
+        h.c_gg = h.c_bx + 14;
+    } else {
+        h.c_gg = o; o += h.nqpad;
+        o = (o + 3) & ~3;
+    }
     h.c_qe = h.c_sw;  // the evaluation point is dead once the site pass writes the wrenches (the LM kernel, which reads it
                       // later in the trip, moves it into its own region)
+    // odd strides (mod 32 banks) so that the chains of one wavefront hit different LDS banks
+    h.stride_regs = o | 1;
+    h.c_r2 = o; o += K > 64 ? h.kpow2 : ((K + 3) & ~3);
     h.c_kp = o; o += 3 * K;
-    // odd stride (mod 32 banks) so that the chains of one wavefront hit different LDS banks
-    if ((o & 1) == 0) o += 1;
-    h.chain_stride = o;
+    h.stride_lds = o | 1;
+    h.chain_stride = h.stride_lds;
     return STAC_OK;
 }
 
 static int q_mb_words(int nkinds, int G) { return (nkinds * G + 3) & ~3; }
+static int q_chain_stride(const PlanHeader &h, int G) { return h.K <= kSiteRounds * G ? h.stride_regs : h.stride_lds; }
 static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
     const int plan_words = (h.total_words + 3) & ~3;  // h is the per-launch copy: total_words = what this launch stages
-    return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * h.chain_stride) * sizeof(float);
+    return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * q_chain_stride(h, G)) * sizeof(float);
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr int kCus = 256;
@@ -653,6 +662,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 fprintf(stderr, "[stac] q_phase: chains=%d speculative (1 chain per wavefront) wpb=%d lds=%zu B/block\n",
                         nchains, sh.wpb, q_lds_bytes(m->h, 8, nkinds, sh.wpb));
             a.mb_words = q_mb_words(nkinds, 8);
+            a.h.chain_stride = q_chain_stride(m->h, 8);
             // chain queue (see below): more clips than resident wavefronts -> a wave that finishes its clip takes the next
             const QShape sres = pick_shape(m->h, 8, nkinds);
             long resident = (long)sres.waves_per_cu * kCus / sh.wpb * sh.wpb;
@@ -687,8 +697,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         }
         if (dbg.verbose)
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
-                    nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), m->h.chain_stride, a.h.total_words);
+                    nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), q_chain_stride(m->h, G), a.h.total_words);
         a.mb_words = q_mb_words(nkinds, G);
+        a.h.chain_stride = q_chain_stride(m->h, G);
         // Straggler hand-off: chains take very different numbers of iterations (the slowest of 10 000 about 1.6x the
         // mean), so the launch would end on a few waves per CU.  Once all but `hcap` chains are done, the rest move to
         // the latency kernel at their next iteration boundary (QArgs::ctl).
@@ -735,6 +746,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             ss.wpe = 2;
             while (ss.wpb > 1 && q_lds_bytes(m->h, 8, nkinds, ss.wpb) > kLdsPerCu) --ss.wpb;
             b.mb_words = q_mb_words(nkinds, 8);
+            b.h.chain_stride = q_chain_stride(m->h, 8);
             int cap2 = 0;
             e = launch_q_phase(b, 8, ss.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, ss.wpb), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
@@ -859,9 +871,11 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     L.npk = (npk_max + 3) & ~3;
     L.maxpd = maxpd_all;
     L.lambda0 = lambda0 > 0.0f ? lambda0 : 1e-2f;
-    int o = h.chain_stride;
+    int o = h.stride_lds;  // the PG layout with the keypoints in LDS
     o = (o + 3) & ~3;
     L.c_qe = o; o += h.nqpad;  // the LM kernel reads the evaluation point after the site pass: not aliased
+    L.c_gg = o; o += std::max(h.nqpad, (h.K + 3) & ~3);  // and keeps the per-site loss terms and the gradient apart from the transforms
+    o = (o + 3) & ~3;
     L.c_sx = o; o += 3 * h.K;
     o = (o + 3) & ~3;
     L.c_jp = o; o += std::max(h.K * L.maxpd * 3, L.npk);
@@ -884,6 +898,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
     a.plan = m->d_blob;
     a.h = m->h;  // total_words (what the launch stages in LDS) is settled with the launch shape below
     a.h.c_qe = m->lm_args.c_qe;
+    a.h.c_gg = m->lm_args.c_gg;
     a.tol = p->tol; a.maxiter = p->maxiter; a.maxls = p->maxls;
     const LmArgs &L = m->lm_args;
 #ifdef STAC_PROFILE

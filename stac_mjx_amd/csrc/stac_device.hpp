@@ -137,7 +137,7 @@ enum : int { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
 // one wave execute in issue order; the fence stops the compiler from moving or caching LDS accesses
 // across the point (it lowers to s_waitcnt lgkmcnt(0)), the wave barrier pins the schedule.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -175,9 +175,11 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
             const Q4 qn = normalize4(ld4(qe + qa), &n);
             st4(qe + qa, qn);  // written back, like MJX
             st4(qlb + 7 * j, qn);
-            jn[j] = n;
-            // the gradient pass needs it after qe's region has been reused: q0 of a quaternion joint is its ordinal
-            st4(qsv + 4 * __builtin_bit_cast(int, lds4(jr + 4).w), qn);
+            // the gradient pass needs |q| and the unit quaternion after qe's region has been reused: they are kept by
+            // the joint's ordinal among the quaternion joints (JointRec::q0 of a free / ball joint)
+            const int qord = __builtin_bit_cast(int, lds4(jr + 4).w);
+            jn[qord] = n;
+            st4(qsv + 4 * qord, qn);
         }
     }
 }

@@ -83,8 +83,15 @@ void q_phase_kernel(const QArgs a) {
     }
     float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn, *qsv = CB + H.c_qsv;
-    float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_gg;
+    float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_r2;
     float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
+    // Sites k = r * G + lg, r < kSiteRounds, belong to this lane: their keypoints and loss terms stay in registers when
+    // that covers all K sites (the host then lays the chain out without the c_kp / c_r2 regions); else through LDS.
+    constexpr int NSR = kSiteRounds;
+    const bool site_regs = K <= NSR * G;
+    float kpr[NSR][3];
+#pragma unroll
+    for (int r = 0; r < NSR; ++r) kpr[r][0] = kpr[r][1] = kpr[r][2] = 0.0f;
     __syncthreads();  // the only workgroup-wide barrier: the plan is shared by the block's waves
 
     const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
@@ -124,6 +131,18 @@ void q_phase_kernel(const QArgs a) {
 
     // initial qpos, keypoints of frame 0, first solve
     size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
+    // keypoints of a frame: this lane's sites into registers, or the whole frame into LDS
+    auto load_kp = [&](const size_t base) {
+        if (site_regs) {
+#pragma unroll
+            for (int r = 0; r < NSR; ++r) {
+                const int k = r * G + lg;
+                if (k < K) { kpr[r][0] = a.kp[base + 3 * k]; kpr[r][1] = a.kp[base + 3 * k + 1]; kpr[r][2] = a.kp[base + 3 * k + 2]; }
+            }
+        } else {
+            for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[base + i];
+        }
+    };
 #pragma unroll
     for (int r = 0; r < NQR; ++r) {
         const int e = r * G + lg;
@@ -132,7 +151,7 @@ void q_phase_kernel(const QArgs a) {
         q0[r] = v;
     }
     if (st != ST_DONE) {
-        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
+        load_kp(kp_chain + (size_t)frame * 3 * K);
         if (!a.single && kind < 2 && !resuming) {  // root pass: q0[:3] = keypoint of the root marker (compute_stac.py:57-59)
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -159,7 +178,7 @@ void q_phase_kernel(const QArgs a) {
             if (kind < 2 && e < 3) v = a.kp[kp_chain + 3 * a.root_kp_idx + e];
             q0[r] = v; x[r] = v; y[r] = v; g[r] = 0.f;
         }
-        for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + i];
+        load_kp(kp_chain);
         st = ST_VG_Y;
     };
     if (resuming) {
@@ -262,8 +281,9 @@ void q_phase_kernel(const QArgs a) {
         const V3 cref = ld3(bx + 7);  // slot 0 = first active body (the root): moments are taken about it
         const bool trunk_w = (!a.single) && kind < 2;
         const int Kpad = (K + 3) & ~3;
-        for (int k = K + lg; k < (K > 64 ? H.kpow2 : Kpad); k += G) r2[k] = 0.0f;  // zero padding of the loss tree
-        for (int k = lg; k < K; k += G) {
+        // one site: world position, weighted residual against the keypoint (kx, ky, kz), loss term; the wrench
+        // (f, (x - c) x f) goes to its place in DFS-site order
+        auto site_term = [&](const int k, const float kx, const float ky, const float kz) -> float {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
             const float *bp = bx + (ss & 0xFFFF) * 7;
@@ -276,9 +296,8 @@ void q_phase_kernel(const QArgs a) {
             }
             // a site without weight: exact zeros, written without looking at its body (which a pruned FK has skipped)
             const bool wz = (w0 == 0.0f) && (w1 == 0.0f) && (w2 == 0.0f);
-            const float rx = wz ? 0.0f : (kpl[3 * k] - sx.x) * w0, ry = wz ? 0.0f : (kpl[3 * k + 1] - sx.y) * w1,
-                        rz = wz ? 0.0f : (kpl[3 * k + 2] - sx.z) * w2;
-            const float term = FMA(rz, rz, FMA(ry, ry, rx * rx));
+            const float rx = wz ? 0.0f : (kx - sx.x) * w0, ry = wz ? 0.0f : (ky - sx.y) * w1,
+                        rz = wz ? 0.0f : (kz - sx.z) * w2;
             if (any_grad) {
                 const V3 f = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
                 V3 tq = cross3(sub3(sx, cref), f);
@@ -287,13 +306,27 @@ void q_phase_kernel(const QArgs a) {
                 st3(sw + 6 * sp, f);
                 st3(sw + 6 * sp + 3, tq);
             }
-            r2[k] = term;
-        }
+            return FMA(rz, rz, FMA(ry, ry, rx * rx));
+        };
+        float loss;
+        if (site_regs) {
+            // pairwise tree over the sites (oracle: tree_sum) as lane butterflies + registers: no LDS, no barrier
+            float term[NSR];
+#pragma unroll
+            for (int r = 0; r < NSR; ++r) {
+                const int k = r * G + lg;
+                term[r] = k < K ? site_term(k, kpr[r][0], kpr[r][1], kpr[r][2]) : 0.0f;
+            }
+            loss = group_tree_sum<G, NSR>(term);
+            wave_sync();
+            PROF_TICK(3);  // sites + loss
+        } else {
+        for (int k = K + lg; k < (K > 64 ? H.kpow2 : Kpad); k += G) r2[k] = 0.0f;  // zero padding of the loss tree
+        for (int k = lg; k < K; k += G) r2[k] = site_term(k, kpl[3 * k], kpl[3 * k + 1], kpl[3 * k + 2]);
         wave_sync();
         PROF_TICK(3);  // sites
         // pairwise tree over the sites (oracle: tree_sum), every lane redundantly from broadcast LDS reads:
         // r2 is padded with zeros to a multiple of 4; levels 1 and 2 inside each float4, then across them.
-        float loss;
         {
             const int n4 = Kpad >> 2;
             if (n4 > 16) {
@@ -334,6 +367,7 @@ void q_phase_kernel(const QArgs a) {
         }
         wave_sync();
         PROF_TICK(4);  // loss sum
+        }
         // gradient of one joint of the evaluation whose arrays start at CBx: subtree wrench of the joint's
         // body = its sites in (body id, site id) order, summed from zero, then the joint formulas
         auto joint_gradient = [&](const int j, float *CBx) {
@@ -374,10 +408,11 @@ void q_phase_kernel(const QArgs a) {
                     } else {
                         tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});
                     }
-                    const Q4 qh = ld4(qsvx + 4 * __builtin_bit_cast(int, lds4(jr + 4).w));  // saved by the pre-pass
+                    const int qord = __builtin_bit_cast(int, lds4(jr + 4).w);  // ordinal among the quaternion joints
+                    const Q4 qh = ld4(qsvx + 4 * qord);  // saved by the pre-pass
                     const V3 u = {qh.x, qh.y, qh.z};
                     const V3 uxt = cross3(u, tl);
-                    const float n = jnx[j];
+                    const float n = jnx[qord];
                     const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
                     ggx[qa] = (-2.0f * dot3(tl, u)) / dn;
                     ggx[qa + 1] = (2.0f * FMA(qh.w, tl.x, -uxt.x)) / dn;
@@ -390,7 +425,7 @@ void q_phase_kernel(const QArgs a) {
         for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
         // (latency mode: a speculative trip computes gradients only for the two evaluations it ends up using, below)
         if (any_grad && !(SPEC && st_in == ST_SPEC)) {
-            // r2 (aliased by gg) has been consumed by the loss sum
+            // gg may sit inside bx (PlanHeader::c_gg): the site pass, the last reader of the transforms, is over
             for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
             wave_sync();
             PROF_TICK(5);  // zero gg
@@ -664,13 +699,13 @@ void q_phase_kernel(const QArgs a) {
                                 }
                             }
                         } else {
-                            for (int i = lg; i < 3 * K; i += G) kpl[i] = a.kp[kp_chain + (size_t)frame * 3 * K + i];
+                            load_kp(kp_chain + (size_t)frame * 3 * K);
                         }
                     } else if (kind < 2) {  // second root pass: seed the translation again (compute_stac.py:80-81)
 #pragma unroll
                         for (int r = 0; r < NQR; ++r) {
                             const int e = r * G + lg;
-                            if (e < 3) q0[r] = kpl[3 * a.root_kp_idx + e];
+                            if (e < 3) q0[r] = a.kp[kp_chain + 3 * a.root_kp_idx + e];  // root passes run on frame 0
                         }
                     }
                     if (st != ST_DONE) {

@@ -210,7 +210,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                 const Q4 qh = ld4(qe + ad + 3);
                 const V3 u = {qh.x, qh.y, qh.z};
                 const V3 uxt = cross3(u, tau);
-                const float n = jn[j];
+                const float n = jn[__builtin_bit_cast(int, lds4(jr + 4).w)];  // by quaternion ordinal
                 const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
                 gg[ad + 3] = (-2.0f * dot3(tau, u)) / dn;
                 gg[ad + 4] = (2.0f * FMA(qh.w, tau.x, -uxt.x)) / dn;
@@ -287,7 +287,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                     if (g2.ty == JFREE) {
                         const int ad = reinterpret_cast<const int *>(jr)[1];
                         g2.qh = ld4(qe + ad + 3);
-                        const float nn = jn[dr.y];
+                        const float nn = jn[__builtin_bit_cast(int, lds4(jr + 4).w)];  // by quaternion ordinal
                         g2.dn = nn + (nn == 0.0f ? 1e-6f : 0.0f);
                     }
                     return g2;

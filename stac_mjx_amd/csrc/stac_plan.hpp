@@ -10,6 +10,9 @@
 namespace stac {
 
 constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
+// A lane of a G-lane group takes the sites k = r * G + lane, r < kSiteRounds: their keypoints and loss terms stay in
+// registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
+constexpr int kSiteRounds = 3;
 
 // Records are 16-byte aligned so the kernel fetches them with ds_read_b128.
 struct BodyRec {      // 12 words
@@ -86,12 +89,15 @@ struct PlanHeader {
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
     int32_t c_bx;      // [(nst+1)*7] pos(3) quat(4) of the stored bodies; entry 0 = world
     int32_t c_ja;      // [naj*7] anchor(3) + quaternion before the joint(4) (the joint pass rotates the axis)
-    int32_t c_jn;      // [nquat_active] |q| of free/ball quaternions, indexed by JointRec order of quaternion joints
+    int32_t c_jn;      // [nqj] |q| of the active free / ball quaternions, by quaternion ordinal (JointRec::q0)
     int32_t c_sw;      // [K*6] site wrench f(3) t(3), by sorted-site position
-    int32_t c_gg;      // [nqpad] gradient out; aliased by r2[K] (per-site loss terms, consumed earlier)
+    int32_t c_gg;      // [nqpad] gradient out: inside c_bx behind the world and root entries when it fits (the body
+                       // transforms are dead once the sites have read them; the joint pass only reads the root position)
     int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place); aliases c_sw in the PG kernel
-    int32_t c_kp;      // [3K] keypoints of the current frame
-    int32_t chain_stride;
+    int32_t c_kp;      // [3K] keypoints of the current frame      } only when a lane group has more than kSiteRounds
+    int32_t c_r2;      // [K padded] per-site loss terms           } sites per lane: else both stay in registers
+    int32_t stride_regs, stride_lds;  // chain stride without / with those two regions (odd)
+    int32_t chain_stride;  // the one of this launch (set per launch by the host)
     int32_t max_width; // bodies in the widest level
     int32_t nst;       // bodies whose transform is stored in LDS (a site or a child on another lane reads it)
     int32_t nqj;       // active quaternion joints (free / ball)
@@ -182,6 +188,8 @@ struct LmArgs {
     float lambda0;
     // extra per-chain LDS regions (float offsets inside the chain region, after the PG layout)
     int32_t c_qe;          // [nqpad] evaluation point (overrides PlanHeader::c_qe for this kernel)
+    int32_t c_gg;          // [max(nqpad, K padded)] gradient out / per-site loss terms (overrides PlanHeader::c_gg, which
+                           // the PG kernel places inside the body transforms)
     int32_t c_sx;          // [3K] site world positions by sorted-site position
     int32_t c_jp;          // [K * maxpd * 3] weighted Jacobian blocks; aliased by the factor H[npk]
     int32_t c_A;           // [npk] J^T W J (+ gauge term), row b holds its root-path columns: A[b * maxpd + pd(a)]
