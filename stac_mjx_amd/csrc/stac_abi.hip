@@ -47,7 +47,7 @@ static int fail(int code, const std::string &msg) {
 // Developer switches: read from the environment ONCE, at stac_model_create, so that a variable
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
-    int flags = -1, spec = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
+    int flags = -1, spec = -1, specg = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
     bool noprune = false, verbose = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
@@ -55,7 +55,7 @@ struct DebugSwitches {
     }
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
-        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE");
+        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG");
         noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
@@ -151,11 +151,12 @@ extern "C" int32_t stac_device_count(void) {
     return n;
 }
 
-// The FK program of the bodies in `need` (null: all active bodies): FkStep records at (micro_level * max_width +
-// position in the level).  Positions are those of the full layout, so a child still follows its parent on one lane.
+// The FK program of the bodies in `need` (null: all active bodies): a header (one FK_ML_* flag word per micro-level,
+// then per position the ql offset of its first step) and the FkStep records at (micro_level * max_width + position in
+// the level).  Positions are those of the full layout, so a child still follows its parent on one lane.
 static std::vector<int32_t> build_fk_program(const stac_model *m, const char *need, int *n_mlev_out) {
     const PlanHeader &h = m->h;
-    const int W = h.max_width, rw = h.fk_rec_words, nlev = h.nlev;
+    const int W = h.max_width, rw = h.fk_rec_words, nlev = h.nlev, hw = h.fk_hdr_words;
     const std::vector<int> &lev_adr = m->h_lev_adr;
     std::vector<int> mfirst(nlev + 1, 0);
     for (int l = 0; l < nlev; ++l) {
@@ -165,43 +166,52 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
         mfirst[l + 1] = mfirst[l] + mm;
     }
     const int n_mlev = std::max((mfirst[nlev] + 1) & ~1, 2);  // even: the kernel runs two steps per loop trip
-    std::vector<int32_t> prog((size_t)n_mlev * W * rw, 0);
     auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    const int32_t ident_ql = h.c_bx + 4;  // the world entry's quaternion (1, 0, 0, 0)
+    std::vector<int32_t> prog((size_t)hw + (size_t)n_mlev * W * rw, 0);
+    for (int ml = 0; ml < n_mlev; ++ml)
+        for (int pp = 0; pp < W; ++pp) {  // a position without work: neutral data, nothing stored
+            int32_t *r = prog.data() + hw + ((size_t)ml * W + pp) * rw;
+            r[3] = -1; r[7] = -1; r[8] = -1; r[9] = ident_ql; r[10] = FK_KIND_PLAIN;
+            if (rw == 16) r[12] = f2i(1.0f);
+        }
+    std::vector<int32_t> ql_of((size_t)n_mlev * W, ident_ql);  // ql offset of every (micro-level, position)
     for (int l = 0; l < nlev; ++l)
         for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) {
             if (need && !need[s]) continue;
             const BodyRec &br = m->h_brec[s];
             const int pp = s - lev_adr[l], njs = m->h_ab_jnum[s], nsteps = std::max(1, njs), xfs = m->h_xf[s];
             for (int i = 0; i < nsteps; ++i) {
-                int32_t *r = prog.data() + ((size_t)(mfirst[l] + i) * W + pp) * rw;
-                int32_t fl = 0;
+                const int ml = mfirst[l] + i;
+                int32_t *r = prog.data() + hw + ((size_t)ml * W + pp) * rw;
+                const int fsh = 8 * (ml & 1);
                 if (i == 0) {
-                    fl |= FK_BODY;
-                    if (!(br.flags & 2)) fl |= FK_PARENT_LDS;
-                    if (!(br.flags & 1)) fl |= FK_BQUAT;
-                    r[1] = br.parent;
-                    for (int c = 0; c < 3; ++c) r[4 + c] = f2i(br.pos[c]);
+                    prog[ml >> 1] |= FK_ML_BODY << fsh;
+                    if (!(br.flags & 1)) prog[ml >> 1] |= FK_ML_BQUAT << fsh;
+                    if (!(br.flags & 2)) {  // the parent's transform comes from LDS (another lane produced it, or the world)
+                        r[3] = h.c_bx + kXf * br.parent;
+                        prog[ml >> 1] |= FK_ML_PARENT_LDS << fsh;
+                    }
+                    for (int c = 0; c < 3; ++c) r[c] = f2i(br.pos[c]);
                     if (rw == 16) for (int c = 0; c < 4; ++c) r[12 + c] = f2i(br.quat[c]);
                 }
                 if (i < njs) {
-                    const int j = m->h_ab_jadr[s] + i;
+                    const int j = m->h_ab_jadr[s] + i, ty = m->h_aj_type[j];
                     const float *jp = m->h_aj_pos.data() + 3 * j;
-                    fl |= FK_JOINT | (m->h_aj_type[j] << FK_JTYPE_SHIFT);
-                    if (jp[0] == 0.0f && jp[1] == 0.0f && jp[2] == 0.0f) fl |= FK_JZERO;
-                    r[2] = j;
-                    for (int c = 0; c < 3; ++c) r[8 + c] = f2i(jp[c]);
-                    r[11] = m->h_aj_qadr[j];
+                    for (int c = 0; c < 3; ++c) r[4 + c] = f2i(jp[c]);
+                    r[7] = h.c_ja + kXf * j;
+                    ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + 4;
+                    prog[ml >> 1] |= FK_ML_JOINT << fsh;
+                    if (jp[0] != 0.0f || jp[1] != 0.0f || jp[2] != 0.0f) prog[ml >> 1] |= FK_ML_JPOS << fsh;
+                    if (ty == STAC_JNT_FREE) { r[10] = FK_KIND_FREE; r[11] = m->h_aj_qadr[j]; prog[ml >> 1] |= FK_ML_SPECIAL << fsh; }
+                    if (ty == STAC_JNT_SLIDE) { r[10] = FK_KIND_SLIDE; r[11] = j; prog[ml >> 1] |= (FK_ML_SPECIAL | FK_ML_JPOS) << fsh; }
                 }
-                if (i == nsteps - 1 && xfs >= 0) fl |= FK_LAST;
-                r[0] = fl;
-                r[7] = std::max(xfs, 0);
+                if (i == nsteps - 1 && xfs >= 0) r[8] = h.c_bx + kXf * xfs;
             }
         }
     for (int ml = 0; ml + 1 < n_mlev; ++ml)
-        for (int pp = 0; pp < W; ++pp) {
-            const int32_t *nx = prog.data() + ((size_t)(ml + 1) * W + pp) * rw;
-            if (nx[0] & FK_JOINT) prog[((size_t)ml * W + pp) * rw + 3] = nx[2];
-        }
+        for (int pp = 0; pp < W; ++pp) prog[hw + ((size_t)ml * W + pp) * rw + 9] = ql_of[(size_t)(ml + 1) * W + pp];
+    for (int pp = 0; pp < W; ++pp) prog[(h.n_mlev_hdr >> 1) + pp] = ql_of[pp];  // first steps: fetched by the prologue
     *n_mlev_out = n_mlev;
     return prog;
 }
@@ -401,6 +411,38 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     quat_adr.push_back(0);
     h.off_quat_adr = put_raw(quat_adr.data(), quat_adr.size());
     h.core_words = (int)B.size();  // what a kernel that walks the levels itself stages in LDS
+    // per-chain LDS layout
+    int o = 0;
+    h.nst = nst;
+    h.nqj = nqj;
+    h.c_bx = o; o += (nst + 1) * kXf;
+    h.c_ja = o; o += naj * kXf;
+    h.c_jn = o; o += std::max(nqj, 1);
+    h.c_qsv = o; o += 4 * nqj;
+    o = (o + 3) & ~3;
+    h.c_sw = o; o += std::max(K * 6, h.nqpad);
+    o = (o + 3) & ~3;
+    h.kpow2 = 1;
+    while (h.kpow2 < K) h.kpow2 <<= 1;
+    // The gradient vector lives inside the body-transform array, behind the world entry and the root's (the joint pass
+    // reads the root position): the transforms are dead once the site pass is over.  Own region if it does not fit.
+    if ((nst + 1) * kXf - 2 * kXf >= h.nqpad) {
+        h.c_gg = h.c_bx + 2 * kXf;
+    } else {
+        h.c_gg = o; o += h.nqpad;
+        o = (o + 3) & ~3;
+    }
+    h.c_qe = h.c_sw;  // the evaluation point is dead once the site pass writes the wrenches (the LM kernel, which reads it
+                      // later in the trip, moves it into its own region)
+    // strides of 4 x odd words: regions stay 16-byte aligned (ds_read_b128 / ds_write_b128) and the chains of one
+    // wavefront start in different banks
+    auto stride_of = [](int words) { const int q = (words + 3) / 4; return 4 * (q | 1); };
+    o = (o + 3) & ~3;
+    h.stride_regs = stride_of(o);
+    h.c_r2 = o; o += K > 64 ? h.kpow2 : ((K + 3) & ~3);
+    h.c_kp = o; o += 3 * K;
+    h.stride_lds = stride_of(o);
+
     {   // FK program (FkStep records, see stac_plan.hpp); a second area of the same size takes the pruned program of
         // the root passes, which depends on the call's trunk keypoints (fill_root_program)
         m->h_brec = brec; m->h_lev_adr = lev_adr; m->h_ab_jadr = ab_jadr; m->h_ab_jnum = ab_jnum; m->h_xf = xf;
@@ -408,6 +450,17 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         bool any_bquat = false;
         for (int s = 0; s < nab; ++s) any_bquat = any_bquat || !(brec[s].flags & 1);
         h.fk_rec_words = any_bquat ? 16 : 12;
+        {   // header of a program area: a flag word per micro-level (of the full program: a pruned one has fewer),
+            // then the first step's ql offset per position
+            int mm = 0;
+            for (int l = 0; l < nlev; ++l) {
+                int ml = 1;
+                for (int s2 = lev_adr[l]; s2 < lev_adr[l + 1]; ++s2) ml = std::max(ml, ab_jnum[s2]);
+                mm += ml;
+            }
+            h.n_mlev_hdr = std::max((mm + 1) & ~1, 2);
+            h.fk_hdr_words = ((h.n_mlev_hdr >> 1) + h.max_width + 3) & ~3;  // one flag word per pair of micro-levels
+        }
         int n_mlev = 0;
         const std::vector<int32_t> prog = build_fk_program(m, nullptr, &n_mlev);
         h.off_fkstep = put_raw(prog.data(), prog.size());
@@ -418,34 +471,6 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     }
     h.total_words = (int)B.size();
 
-    // per-chain LDS layout
-    int o = 0;
-    h.nst = nst;
-    h.nqj = nqj;
-    h.c_bx = o; o += (nst + 1) * 7;
-    h.c_ja = o; o += naj * 7;
-    h.c_jn = o; o += std::max(nqj, 1);
-    h.c_qsv = o; o += 4 * nqj;
-    o = (o + 3) & ~3;
-    h.c_sw = o; o += std::max(K * 6, h.nqpad);
-    o = (o + 3) & ~3;
-    h.kpow2 = 1;
-    while (h.kpow2 < K) h.kpow2 <<= 1;
-    // The gradient vector lives inside the body-transform array, behind the world entry and the root's (the joint pass
-    // reads the root position): the transforms are dead once the site pass is over.  Own region if it does not fit.
-    if ((nst + 1) * 7 - 14 >= h.nqpad) {
-        h.c_gg = h.c_bx + 14;
-    } else {
-        h.c_gg = o; o += h.nqpad;
-        o = (o + 3) & ~3;
-    }
-    h.c_qe = h.c_sw;  // the evaluation point is dead once the site pass writes the wrenches (the LM kernel, which reads it
-                      // later in the trip, moves it into its own region)
-    // odd strides (mod 32 banks) so that the chains of one wavefront hit different LDS banks
-    h.stride_regs = o | 1;
-    h.c_r2 = o; o += K > 64 ? h.kpow2 : ((K + 3) & ~3);
-    h.c_kp = o; o += 3 * K;
-    h.stride_lds = o | 1;
     h.chain_stride = h.stride_lds;
     return STAC_OK;
 }
@@ -458,6 +483,8 @@ static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr int kCus = 256;
+// latency mode: up to this many chains a chain is spread over 8 / 4 wavefronts of a workgroup (else one per chain)
+constexpr long kSpec64MaxChains = 256, kSpec32MaxChains = 512;
 
 // Wavefronts per workgroup: the waves of a block share one copy of the plan, so more chains fit the
 // 160 KiB of a CU.  Returns the wpb (1..8) that maximises resident chains per CU for this G.
@@ -498,6 +525,38 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_need
     return best;
 }
 
+// ---- latency (speculative) mode: eight evaluation roles of G lanes per chain -------------------------------------------
+// G = 8: one chain per wavefront, `chains` wavefronts per workgroup; G = 32 / 64: one chain per workgroup of 4 / 8
+// wavefronts.  A chain's LDS block = 8 role regions + the exchange area (accept flags, losses, two gradients).
+static int spec_xch_words(const PlanHeader &h) { return 64 + 4 * h.nqpad + 4; }
+static size_t spec_lds_bytes(const PlanHeader &h, int G, int nkinds, int chains) {
+    const int plan_words = (h.total_words + 3) & ~3;
+    return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (8 * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float);
+}
+struct SpecShape { int G, chains_per_block, waves_per_block; long resident; };  // resident = chains the chip holds at once
+static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nchains = -1) {
+    constexpr size_t kGranule = 1280;
+    SpecShape best{G, 0, 0, 0};
+    if (G == 8) {  // 256-VGPR kernel: two waves per SIMD, eight per CU
+        for (int c = 1; c <= 8; ++c) {
+            size_t lds = spec_lds_bytes(h, 8, nkinds, c);
+            if (lds > kLdsPerCu) break;
+            lds = (lds + kGranule - 1) / kGranule * kGranule;
+            const int blocks = std::min((int)(kLdsPerCu / lds), 8 / c);
+            const long res = (long)blocks * c * kCus;
+            if (res > best.resident) best = SpecShape{8, c, c, res};
+            if (nchains >= 0 && res >= nchains) return SpecShape{8, c, c, res};  // small workgroups spread over more CUs
+        }
+        return best;
+    }
+    const int nw = G / 8;  // 256-VGPR kernels as well (the 128-VGPR builds spill > 100 registers): eight waves per CU
+    size_t lds = spec_lds_bytes(h, G, nkinds, 1);
+    if (lds > kLdsPerCu) return best;
+    lds = (lds + kGranule - 1) / kGranule * kGranule;
+    const int blocks = std::min((int)(kLdsPerCu / lds), 8 / nw);
+    return SpecShape{G, 1, nw, (long)blocks * kCus};
+}
+
 extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     if (!t) { fail(STAC_ERR_INVALID, "null tables"); return nullptr; }
     if (stac_device_count() <= 0) {
@@ -530,8 +589,7 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
     {   // hand-off buffer of the straggler hand-off at its maximum size (one entry per wavefront the latency kernel
         // can hold resident), so that no launch ever reallocates (= waits for the device)
-        const QShape ss = pick_shape(m->h, 8, 1);
-        m->hand_cap = ss.wpb ? ss.waves_per_cu * kCus : 0;
+        m->hand_cap = (int)pick_spec_shape(m->h, 8, 1).resident;
         if (m->hand_cap > 0)
             chk(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)m->hand_cap * (3 * (size_t)m->h.nqpad + 12) * sizeof(float)));
     }
@@ -618,8 +676,8 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
-        const QShape ss = pick_shape(m->h, 8, nkinds);  // one chain per wave, eight 8-lane evaluation groups
-        if (ss.wpb && (long)nchains * 10 <= (long)ss.waves_per_cu * kCus * 23) return 0;
+        const SpecShape ss = pick_spec_shape(m->h, 8, nkinds);  // one chain per wave, eight 8-lane evaluation groups
+        if (ss.resident && (long)nchains * 10 <= ss.resident * 23) return 0;
     }
     const QShape s16 = pick_shape(m->h, 16, nkinds);
     if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 45) return 16;
@@ -654,24 +712,32 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     if (dbg.spec >= 0) spec = a.single ? 0 : dbg.spec;
     if (G == 0) G = spec ? 64 : 32;
     if (spec) {
-        QShape sh = pick_shape(m->h, 8, nkinds, nchains);  // 8 groups of 8 lanes: same LDS as eight 8-lane chains
-        if (sh.wpb) {
-            sh.wpe = 2;
-            while (sh.wpb > 1 && q_lds_bytes(m->h, 8, nkinds, sh.wpb) > kLdsPerCu) --sh.wpb;
+        // lanes per evaluation role: with very few chains every chain gets a whole workgroup of 4 or 8 wavefronts
+        // (measured, rodent, 250-frame clips: DESIGN.md 2.1), else one wavefront per chain
+        int sg = 8;
+        {
+            const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(m->h, 32, nkinds);
+            if (s64.resident && (long)nchains <= kSpec64MaxChains) sg = 64;
+            else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
+        }
+        if (dbg.specg == 8 || dbg.specg == 32 || dbg.specg == 64) sg = dbg.specg;
+        if (m->h.nq > sg * (sg == 8 ? 32 : sg == 32 ? 8 : 4)) sg = 8;  // no instantiation that wide: back to one wave per chain
+        const SpecShape sh = pick_spec_shape(m->h, sg, nkinds, nchains);
+        if (sh.chains_per_block) {
+            const size_t lds = spec_lds_bytes(m->h, sg, nkinds, sh.chains_per_block);
             if (dbg.verbose)
-                fprintf(stderr, "[stac] q_phase: chains=%d speculative (1 chain per wavefront) wpb=%d lds=%zu B/block\n",
-                        nchains, sh.wpb, q_lds_bytes(m->h, 8, nkinds, sh.wpb));
-            a.mb_words = q_mb_words(nkinds, 8);
-            a.h.chain_stride = q_chain_stride(m->h, 8);
-            // chain queue (see below): more clips than resident wavefronts -> a wave that finishes its clip takes the next
-            const QShape sres = pick_shape(m->h, 8, nkinds);
-            long resident = (long)sres.waves_per_cu * kCus / sh.wpb * sh.wpb;
-            if (dbg.queue > 0 && dbg.queue < nchains) resident = (long)(dbg.queue + sh.wpb - 1) / sh.wpb * sh.wpb;
+                fprintf(stderr, "[stac] q_phase: chains=%d speculative, %d lanes per evaluation (%d wavefront(s) per chain), %d chain(s) per workgroup, lds=%zu B/block, resident=%ld\n",
+                        nchains, sg, std::max(sg / 8, 1), sh.chains_per_block, lds, sh.resident);
+            a.mb_words = q_mb_words(nkinds, sg);
+            a.h.chain_stride = q_chain_stride(m->h, sg);
+            // chain queue (see below): more clips than resident chain slots -> the roles of a finished clip take the next
+            long resident = pick_spec_shape(m->h, sg, nkinds).resident / sh.chains_per_block * sh.chains_per_block;
+            if (dbg.queue > 0 && dbg.queue < nchains) resident = (long)(dbg.queue + sh.chains_per_block - 1) / sh.chains_per_block * sh.chains_per_block;
             if ((long)nchains > resident && dbg.queue != 0) {
                 HIP_TRY(launch_ctl_init(m->d_ctl, 0, 0x7fffffff, 0, 0, (int)resident, s));
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
-            e = launch_q_phase(a, 8, sh.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, sh.wpb), s, &cap);
+            e = launch_q_phase(a, sg, sh.waves_per_block, 2, 1, lds, s, &cap);
             a.ctl = nullptr; a.queue_slots = 0;
         }
     }
@@ -705,8 +771,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // the latency kernel at their next iteration boundary (QArgs::ctl).
         int hcap = 0;
         if (!a.single && !(a.flags & 3) && m->h.max_width <= 8) {
-            const QShape ss = pick_shape(m->h, 8, nkinds);
-            const int spec_cap = ss.wpb ? ss.waves_per_cu * kCus : 0;
+            const int spec_cap = (int)pick_spec_shape(m->h, 8, nkinds).resident;
             // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
             if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
             if (dbg.handoff >= 0) hcap = spec_cap ? std::min(dbg.handoff, nchains) : 0;
@@ -721,8 +786,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             if (!a.single && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
         }
         if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= 8 && dbg.handoff < 0) {
-            const QShape ss = pick_shape(m->h, 8, nkinds);
-            hcap = std::min(ss.wpb ? ss.waves_per_cu * kCus : 0, nchains / 5);  // with a queue the tail is one round: hand off
+            hcap = std::min((int)pick_spec_shape(m->h, 8, nkinds).resident, nchains / 5);  // with a queue the tail is one round: hand off
         }
         hcap = std::min(hcap, m->hand_cap);
         // A group that hands its chain off stops taking chains from the queue, so hand-off must not begin while the
@@ -742,15 +806,13 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             b.resume = 1; b.resume_slots = hcap;
             b.h = m->h;
             b.flags = a.flags & ~2;
-            QShape ss = pick_shape(m->h, 8, nkinds, hcap);
-            ss.wpe = 2;
-            while (ss.wpb > 1 && q_lds_bytes(m->h, 8, nkinds, ss.wpb) > kLdsPerCu) --ss.wpb;
+            const SpecShape ss = pick_spec_shape(m->h, 8, nkinds, hcap);
             b.mb_words = q_mb_words(nkinds, 8);
             b.h.chain_stride = q_chain_stride(m->h, 8);
             int cap2 = 0;
-            e = launch_q_phase(b, 8, ss.wpb, 2, 1, q_lds_bytes(m->h, 8, nkinds, ss.wpb), s, &cap2);
+            e = launch_q_phase(b, 8, ss.waves_per_block, 2, 1, spec_lds_bytes(m->h, 8, nkinds, ss.chains_per_block), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
-            if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.wpb);
+            if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.waves_per_block);
         }
         a.ctl = nullptr; a.hand = nullptr; a.queue_slots = 0;
         if (cap) break;  // an instantiation with this many lanes holds nq
@@ -764,10 +826,11 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         (void)hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost);
         static const char *names[] = {"loop", "stage", "fk", "sites", "loss_sum", "zero_gg", "joint_grad", "trans_sums", "accept_fused", "end_solve", "prepass", "-"};
         unsigned long long tot = 0;
-        for (int i = 0; i < 12; ++i) tot += h[i];
+        for (int i = 0; i < 11; ++i) tot += h[i];
         fprintf(stderr, "[stac profile] G=%d", G);
-        for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
-        fprintf(stderr, " total_wave_cycles=%.3g\n", (double)tot);
+        for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        fprintf(stderr, " total_wave_cycles=%.3g wave_trips=%.4g cycles_per_wave_trip=%.0f fk_cycles_per_wave_trip=%.0f\n", (double)tot, (double)h[11],
+                (double)tot / (double)(h[11] ? h[11] : 1), (double)h[2] / (double)(h[11] ? h[11] : 1));
     }
 #endif
     return STAC_OK;
@@ -884,8 +947,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     L.c_b = o; o += L.n_max;
     L.c_d = o; o += L.n_max + 2 * L.maxpd;  // step vector + two scratch rows of the L^T D L pivot loop
     L.c_fz = o; o += L.n_max;
-    if ((o & 1) == 0) o += 1;
-    L.chain_stride = o;
+    L.chain_stride = 4 * (((o + 3) / 4) | 1);  // 16-byte aligned regions, chains spread over the banks
     return STAC_OK;
 }
 

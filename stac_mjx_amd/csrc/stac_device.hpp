@@ -121,6 +121,7 @@ enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4 };
         pacc[i] += pt1 - pt0;                                    \
         pt0 = pt1;                                               \
     } while (0)
+#define PROF_TRIP pacc[11] += 1
 #define PROF_FLUSH(a)                                                                     \
     do {                                                                                  \
         if (a.prof && lane == 0)                                                          \
@@ -128,6 +129,7 @@ enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4 };
     } while (0)
 #else
 #define PROF_DECL
+#define PROF_TRIP
 #define PROF_TICK(i)
 #define PROF_FLUSH(a)
 #endif
@@ -144,6 +146,11 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast<const int4 *>(p); }
+// transform entries (kXf words, 16-byte aligned: stac_plan.hpp): position in words 0-2, quaternion in words 4-7
+__device__ __forceinline__ V3 ld_tpos(const float *p) { const float4 v = lds4(p); return {v.x, v.y, v.z}; }
+__device__ __forceinline__ Q4 ld_tquat(const float *p) { const float4 v = lds4(p + 4); return {v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st_tpos(float *p, V3 v) { *reinterpret_cast<float4 *>(p) = float4{v.x, v.y, v.z, 0.0f}; }
+__device__ __forceinline__ void st_tquat(float *p, Q4 q) { *reinterpret_cast<float4 *>(p + 4) = float4{q.w, q.x, q.y, q.z}; }
 
 // ------------------------------------------------------------------------------------------------
 // forward kinematics of one chain out of LDS (shared by the PG and the LM kernel)
@@ -154,7 +161,7 @@ __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
 __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf) {
     const float *jrec = P + H.off_joint;
-    float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *qlb = CBc + H.c_ja + 3, *qsv = CBc + H.c_qsv;
+    float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *ja = CBc + H.c_ja, *qsv = CBc + H.c_qsv;
     for (int j = lf; j < H.naj; j += gf) {
         const float *jr = jrec + 12 * j;
         const int4 ji = lds4i(jr);  // type, qadr, slo, shi
@@ -165,16 +172,16 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
             const float angle = qe[ad] - jp4.w;
             float sn, cs;
             sincos_(angle * 0.5f, &sn, &cs);
-            st4(qlb + 7 * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
+            st_tquat(ja + kXf * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
         } else if (ty == JSLIDE) {
             const float4 jp4 = lds4(jr + 4);
-            qlb[7 * j] = qe[ad] - jp4.w;
+            ja[kXf * j + 4] = qe[ad] - jp4.w;
         } else {
             const int qa = ty == JFREE ? ad + 3 : ad;
             float n;
             const Q4 qn = normalize4(ld4(qe + qa), &n);
             st4(qe + qa, qn);  // written back, like MJX
-            st4(qlb + 7 * j, qn);
+            st_tquat(ja + kXf * j, qn);
             // the gradient pass needs |q| and the unit quaternion after qe's region has been reused: they are kept by
             // the joint's ordinal among the quaternion joints (JointRec::q0 of a free / ball joint)
             const int qord = __builtin_bit_cast(int, lds4(jr + 4).w);
@@ -195,7 +202,7 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
     const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
     const float *brec = P + H.off_body, *jrec = P + H.off_joint;
     float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
-    const float *qe = CBc + H.c_qe, *qlb = CBc + H.c_ja + 3;
+    const float *qe = CBc + H.c_qe;
     const bool carry_ok = H.max_width <= gf;  // every level is a single pass
     V3 cpos = {0.f, 0.f, 0.f};
     Q4 cquat = {1.f, 0.f, 0.f, 0.f};
@@ -208,9 +215,9 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
             V3 ppos = cpos;
             Q4 pquat = cquat;
             if (!(carry_ok && (bi.w & 2))) {
-                const float *pp = bx + bi.x * 7;
-                ppos = ld3(pp);
-                pquat = ld4(pp + 3);
+                const float *pp = bx + bi.x * kXf;
+                ppos = ld_tpos(pp);
+                pquat = ld_tquat(pp);
             }
             V3 pos = add3(ppos, rotate(V3{bp.x, bp.y, bp.z}, pquat));
             Q4 quat = pquat;  // product with an identity body_quat is exact: skipped
@@ -231,7 +238,7 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
                 const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
                 V3 anchor = pos;
                 if (ty == JHINGE || ty == JBALL) {
-                    const Q4 qloc = ld4(qlb + 7 * j);
+                    const Q4 qloc = ld_tquat(ja + kXf * j);
                     if (!jzero) anchor = add3(rotate(jp, quat), pos);
                     quat = qmul(quat, qloc);
                     if (!jzero) pos = sub3(anchor, rotate(jp, quat));
@@ -243,18 +250,18 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
                     if (!jzero) anchor = add3(rotate(jp, quat), pos);
                     const float4 ja4 = lds4(jr + 8);
                     const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
-                    const float d = qlb[7 * j];
+                    const float d = ja[kXf * j + 4];
                     pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
                 }
                 if (store_ja) {
-                    st3(ja + 7 * j, anchor);
-                    st4(ja + 7 * j + 3, prequat);
+                    st_tpos(ja + kXf * j, anchor);
+                    st_tquat(ja + kXf * j, prequat);
                 }
             }
             const int xf = (int)((unsigned)bi.w >> 16);
             if (xf != 0xFFFF) {  // somebody reads it back (a site, or a child on another lane)
-                st3(bx + xf * 7, pos);
-                st4(bx + xf * 7 + 3, quat);
+                st_tpos(bx + xf * kXf, pos);
+                st_tquat(bx + xf * kXf, quat);
             }
             cpos = pos;
             cquat = quat;
@@ -264,71 +271,75 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
 }
 
 // The same kinematics driven by the FK "program" (FkStep records, stac_plan.hpp): one fixed-size record per
-// (micro-level, lane position), so the record and the joint-local quaternion of step k+1 are fetched while
-// step k computes and the serial chain holds no dependent LDS round trip except a parent transform that
-// another lane produced (branch points of the tree).  Requires max_width <= gf.  Bit-identical to fk_levels.
+// (micro-level, lane position), fetched one step ahead together with the step's joint-local quaternion.  Every step
+// is the same straight-line hinge arithmetic on neutral data where a part does not apply (zeros / identity: exact
+// no-ops), so the common step has no divergent branch, no select and no address arithmetic beyond base + offset; a
+// per-micro-level flag word (wave-uniform) says when some position needs a parent that another lane produced or has
+// a free / slide joint.  Requires max_width <= gf.  Bit-identical to fk_levels.
 struct FkRegs {
-    int4 r0;           // flags, parent, j, jnext
-    float4 r1, r2, r3; // body_pos | xf, jnt_pos | qadr, body_quat
-    Q4 ql;             // joint-local quaternion of the step's joint
+    float4 r0;  // bpos | par_off
+    float4 r1;  // jpos | ja_off
+    int4 r2;    // xf_off, ql_next, kind, aux
+    float4 r3;  // body_quat (records of 16 words)
+    Q4 ql;      // joint-local quaternion of the step's joint (identity: none)
 };
 template <int RW>
-__device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const float *qlb, const int jq, const bool on) {
-    R.r0 = lds4i(rec);
+__device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const float *CBc, const int ql_off) {
+    R.r0 = lds4(rec);
     R.r1 = lds4(rec + 4);
-    R.r2 = lds4(rec + 8);
+    R.r2 = lds4i(rec + 8);
     if constexpr (RW == 16) R.r3 = lds4(rec + 12);
-    if (!on) R.r0.x = 0;
-    R.ql = ld4(qlb + 7 * jq);
+    { const float4 v = lds4(CBc + ql_off); R.ql = Q4{v.x, v.y, v.z, v.w}; }  // ql_off = words 4-7 of a transform entry: one ds_read_b128
 }
-// One step: fetch the next step's record into N (its joint index is this record's jnext), then run this one.
+// One step: fetch the next step's record into N (its ql offset is in this record), then run this one.
+// `on`: the lane has a position in the program (the others run position 0's data, with nothing loaded or stored).
 template <int RW>
-__device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float *next_rec, const bool on, V3 &pos, Q4 &quat,
-                                        float *bx, float *ja, const float *qe, const float *jrec, const bool store_ja) {
-    fk_fetch<RW>(N, next_rec, ja + 3, R.r0.w, on);
-    const int fl = R.r0.x;
-    if (fl & FK_BODY) {
-        if (fl & FK_PARENT_LDS) {
-            const float *pp = bx + R.r0.y * 7;
-            pos = ld3(pp);
-            quat = ld4(pp + 3);
-        }
-        pos = add3(pos, rotate(V3{R.r1.x, R.r1.y, R.r1.z}, quat));
-        if constexpr (RW == 16) {
-            if (fl & FK_BQUAT) quat = qmul(quat, Q4{R.r3.x, R.r3.y, R.r3.z, R.r3.w});  // identity: exact, skipped
+__device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float *next_rec, const int mlf, const bool on,
+                                        V3 &pos, Q4 &quat, float *CBc, const float *qe, const float *jrec, const bool store_ja) {
+    fk_fetch<RW>(N, next_rec, CBc, R.r2.y);
+    if (mlf & FK_ML_PARENT_LDS) {  // wave-uniform: some position starts a body whose parent another lane (or nobody) produced
+        const int po = __builtin_bit_cast(int, R.r0.w);
+        if (on && po >= 0) {
+            pos = ld_tpos(CBc + po);
+            quat = ld_tquat(CBc + po);
         }
     }
-    if (fl & FK_JOINT) {
-        const int j = R.r0.z, ty = (fl >> FK_JTYPE_SHIFT) & 3;
-        const V3 jp = {R.r2.x, R.r2.y, R.r2.z};
-        const bool jzero = fl & FK_JZERO;  // rotate(0, q) is a zero vector: anchor = pos, pos stays (exact)
-        const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
-        V3 anchor = pos;
-        if (ty == JHINGE || ty == JBALL) {
-            if (!jzero) anchor = add3(rotate(jp, quat), pos);
-            quat = qmul(quat, R.ql);
-            if (!jzero) pos = sub3(anchor, rotate(jp, quat));
-        } else if (ty == JFREE) {
-            const int ad = __builtin_bit_cast(int, R.r2.w);
-            anchor = ld3(qe + ad);
+    // every part below is skipped when NO position of this micro-level needs it (wave-uniform flags): the skipped
+    // arithmetic would be an exact no-op on neutral data
+    if (mlf & FK_ML_BODY) pos = add3(pos, rotate(V3{R.r0.x, R.r0.y, R.r0.z}, quat));
+    if constexpr (RW == 16) {
+        if (mlf & FK_ML_BQUAT) quat = qmul(quat, Q4{R.r3.x, R.r3.y, R.r3.z, R.r3.w});
+    }
+    const V3 jp = {R.r1.x, R.r1.y, R.r1.z};
+    const V3 pos0 = pos;
+    const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
+    V3 anchor = pos;
+    if (mlf & FK_ML_JOINT) {
+        if (mlf & FK_ML_JPOS) anchor = add3(rotate(jp, quat), pos);
+        quat = qmul(quat, R.ql);
+        if (mlf & FK_ML_JPOS) pos = sub3(anchor, rotate(jp, quat));
+    }
+    if (mlf & FK_ML_SPECIAL) {  // wave-uniform: some position has a free or a slide joint in this micro-level
+        if (on && R.r2.z == FK_KIND_FREE) {
+            anchor = ld3(qe + R.r2.w);
             pos = anchor;
             quat = R.ql;  // normalised by the pre-pass
-        } else {  // slide
-            if (!jzero) anchor = add3(rotate(jp, quat), pos);
-            const float4 ja4 = lds4(jrec + 12 * j + 8);
-            const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
+        } else if (on && R.r2.z == FK_KIND_SLIDE) {
+            const float4 ja4 = lds4(jrec + 12 * R.r2.w + 8);
+            const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, prequat);
             const float d = R.ql.w;
-            pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
-        }
-        if (store_ja) {
-            st3(ja + 7 * j, anchor);
-            st4(ja + 7 * j + 3, prequat);
+            quat = prequat;
+            pos = {FMA(axis.x, d, pos0.x), FMA(axis.y, d, pos0.y), FMA(axis.z, d, pos0.z)};
         }
     }
-    if (fl & FK_LAST) {
-        const int xf = __builtin_bit_cast(int, R.r1.w);
-        st3(bx + xf * 7, pos);
-        st4(bx + xf * 7 + 3, quat);
+    const int jo = __builtin_bit_cast(int, R.r1.w);
+    if (store_ja && on && jo >= 0) {
+        st_tpos(CBc + jo, anchor);
+        st_tquat(CBc + jo, prequat);
+    }
+    if (on && R.r2.x >= 0) {
+        st_tpos(CBc + R.r2.x, pos);
+        st_tquat(CBc + R.r2.x, quat);
     }
     wave_sync();
 }
@@ -337,23 +348,27 @@ __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, 
                                            const bool active, const bool store_ja, const int prog_off, const int n_ml) {
     const int W = H.max_width;
     const bool on = active && lf < W;
-    const float *sp = P + prog_off + RW * (on ? lf : 0);
+    // header: one word per PAIR of micro-levels (flags of step ml | flags of step ml + 1 << 8), then the ql offset of
+    // every position's first step
+    const int *hdr = reinterpret_cast<const int *>(P + prog_off);
+    const float *sp = P + prog_off + H.fk_hdr_words + RW * (on ? lf : 0);
     const float *jrec = P + H.off_joint;
-    float *bx = CBc + H.c_bx, *ja = CBc + H.c_ja;
     const float *qe = CBc + H.c_qe;
     V3 pos = {0.f, 0.f, 0.f};  // the lane's running transform: a body that follows its parent on the same lane
     Q4 quat = {1.f, 0.f, 0.f, 0.f};  // starts from it without touching LDS
     FkRegs A, B;
     A.r3 = B.r3 = float4{1.f, 0.f, 0.f, 0.f};
-    fk_fetch<RW>(A, sp, ja + 3, 0, on);
-    A.ql = ld4(ja + 3 + 7 * A.r0.z);
+    fk_fetch<RW>(A, sp, CBc, hdr[(H.n_mlev_hdr >> 1) + (on ? lf : 0)]);
     const int stride = RW * W;
+    int fl_v = hdr[0];
     // two steps per trip so that the fetched record never has to be copied (n_mlev is even: padded by the host)
     for (int ml = 0; ml < n_ml; ml += 2) {
+        const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+        fl_v = hdr[(ml >> 1) + 1];  // next pair (one word of slack behind the last pair: the first-step table follows)
         sp += stride;
-        fk_step<RW>(A, B, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
+        fk_step<RW>(A, B, sp, fl & 255, on, pos, quat, CBc, qe, jrec, store_ja);
         if (ml + 2 < n_ml) sp += stride;
-        fk_step<RW>(B, A, sp, on, pos, quat, bx, ja, qe, jrec, store_ja);
+        fk_step<RW>(B, A, sp, (fl >> 8) & 255, on, pos, quat, CBc, qe, jrec, store_ja);
     }
 }
 

@@ -40,19 +40,25 @@ namespace stac {
 // WPE = waves per SIMD the register allocation is capped for (2 -> 256 VGPRs, 3 -> 168 VGPRs in workgroups of
 // up to ten waves, 4 -> 128 VGPRs): the host picks the variant that lets the most chains be resident.
 //
-// SPEC (latency mode, G == 8 only): the eight lane groups of a wavefront all work on ONE chain.  After a
-// bootstrap evaluation of f, grad f at y, every trip evaluates in parallel the four line-search candidates
-// cand_c = clip(y - (eta / 2^c) g), c = 0..3 (groups 0-3, with gradient) and the four momentum points
-// y_next(c) they would lead to (groups 4-7).  The first acceptable candidate c* is taken exactly as the
-// sequential algorithm would; its gradient gives the stopping residual and group 4+c* already holds
-// f, grad f at the next y: one trip per PG iteration instead of three, identical arithmetic per evaluation.
-// The joint pass of such a trip runs after the choice, for those two evaluations only, on all 64 lanes.
+// SPEC (latency mode): EIGHT lane groups of G lanes work on ONE chain -- the eight groups of one wavefront
+// (G = 8), or, when there are so few chains that the chip would stay empty, the groups of G / 8 wavefronts of
+// one workgroup (G = 32: 4 waves, G = 64: 8 waves per chain; every phase outside the serial FK then gets
+// 4-8 x the lanes and the waves overlap each other's LDS waits).  After a bootstrap evaluation of f, grad f at
+// y, every trip evaluates in parallel the four line-search candidates cand_c = clip(y - (eta / 2^c) g),
+// c = 0..3 (roles 0-3) and the four momentum points y_next(c) they would lead to (roles 4-7).  The first
+// acceptable candidate c* is taken exactly as the sequential algorithm would; its gradient gives the stopping
+// residual and role 4+c* already holds f, grad f at the next y: one trip per PG iteration instead of three,
+// identical arithmetic per evaluation.  The joint pass of such a trip runs after the choice, for those two
+// evaluations only, by all 64 lanes of the wave(s) that own them.  The solver state is replicated in every
+// role; roles exchange {accept flag, loss} and the two gradients through a small per-chain LDS area
+// (double-buffered by trip parity, so two workgroup barriers per trip suffice).
 template <int G, int NQR, int WPE, bool SPEC>
 __global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
-    static_assert(!SPEC || G == 8, "speculative mode uses the 8 groups of 8 lanes of one wavefront");
+    static_assert(!SPEC || G == 8 || G == 16 || G == 32 || G == 64, "speculative mode: 8 roles of G lanes");
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
+    constexpr int NW = SPEC ? (G >= 8 ? G / 8 : 1) : 1;  // SPEC: wavefronts per chain (one chain per workgroup when > 1)
     const PlanHeader &H = a.h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int grp = lane / G, lg = lane % G;
@@ -81,7 +87,18 @@ void q_phase_kernel(const QArgs a) {
         }
         MB[i] = bits;
     }
-    float *CB = lds + plan_words + a.mb_words + (wave * CPW + grp) * H.chain_stride;  // this chain's region
+    // SPEC: a chain's block = 8 role regions + the exchange area; the block's waves share it (NW > 1) or own one each
+    const int xch_words = 64 + 4 * nqpad + 4;
+    const int cblock_words = 8 * H.chain_stride + xch_words;
+    float *CBw = lds + plan_words + a.mb_words + (SPEC ? (NW > 1 ? 0 : wave) * cblock_words : wave * CPW * H.chain_stride);
+    const int role = SPEC ? (NW > 1 ? wave * CPW + grp : grp) : grp;
+    float *CB = CBw + (SPEC ? role : grp) * H.chain_stride;  // this evaluation's (chain's) region
+    float *XB = CBw + 8 * H.chain_stride;  // SPEC: [2][8][4] {accept, loss}, [2][2][nqpad] gradients, [4] queue word
+    int trip_parity = 0;
+    auto chain_sync = [&]() {  // all lanes that work on this chain
+        if constexpr (NW > 1) __syncthreads();
+        else wave_sync();
+    };
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn, *qsv = CB + H.c_qsv;
     float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_r2;
     float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
@@ -100,14 +117,14 @@ void q_phase_kernel(const QArgs a) {
     const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
     // ---- per-chain solver state (uniform inside a group) ------------------------------------------
-    const int slot_id = SPEC ? (blockIdx.x * wpb + wave) : (blockIdx.x * wpb + wave) * CPW + grp;
+    const int slot_id = SPEC ? (NW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * wpb + wave)) : (int)(blockIdx.x * wpb + wave) * CPW + grp;
     const int hstride = 3 * nqpad + 12;
     // resume = 1: this launch continues the chains that the throughput kernel handed off (QArgs::ctl / hand)
     const bool resuming = a.resume != 0 && slot_id < a.ctl[2] && slot_id < a.ctl[3];
     const float *hs = a.hand + (size_t)(resuming ? slot_id : 0) * hstride;
     const int *hi = reinterpret_cast<const int *>(hs + 3 * nqpad);
     int chain = a.resume ? (resuming ? hi[0] : a.C) : slot_id;  // with a chain queue (QArgs::queue_slots) a group takes
-    const int role = grp;                                        // further chains when it has finished one
+                                                                 // further chains when it has finished one
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
     int frame = 0, iter = 0, nls = 0;
@@ -127,7 +144,7 @@ void q_phase_kernel(const QArgs a) {
     const float eps = 1.1920929e-7f;
 
     // bx[0] = world
-    if (lg == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 0.f; bx[3] = 1.f; bx[4] = 0.f; bx[5] = 0.f; bx[6] = 0.f; }
+    if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
 
     // initial qpos, keypoints of frame 0, first solve
     size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
@@ -194,6 +211,7 @@ void q_phase_kernel(const QArgs a) {
     // ================================= main loop: one q_loss evaluation per trip ==================
     while (__any(st != ST_DONE)) {
         PROF_TICK(0);  // loop control
+        PROF_TRIP;
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
@@ -278,7 +296,7 @@ void q_phase_kernel(const QArgs a) {
 
         PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
-        const V3 cref = ld3(bx + 7);  // slot 0 = first active body (the root): moments are taken about it
+        const V3 cref = ld_tpos(bx + kXf);  // entry 1 = first active body (the root): moments are taken about it
         const bool trunk_w = (!a.single) && kind < 2;
         const int Kpad = (K + 3) & ~3;
         // one site: world position, weighted residual against the keypoint (kx, ky, kz), loss term; the wrench
@@ -286,8 +304,8 @@ void q_phase_kernel(const QArgs a) {
         auto site_term = [&](const int k, const float kx, const float ky, const float kz) -> float {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
-            const float *bp = bx + (ss & 0xFFFF) * 7;
-            const V3 sx = add3(ld3(bp), rotate(V3{sr.x, sr.y, sr.z}, ld4(bp + 3)));
+            const float *bp = bx + (ss & 0xFFFF) * kXf;
+            const V3 sx = add3(ld_tpos(bp), rotate(V3{sr.x, sr.y, sr.z}, ld_tquat(bp)));
             float w0, w1, w2;
             if (a.single) {
                 w0 = a.kpw3[3 * k] ? 1.f : 0.f; w1 = a.kpw3[3 * k + 1] ? 1.f : 0.f; w2 = a.kpw3[3 * k + 2] ? 1.f : 0.f;
@@ -370,10 +388,9 @@ void q_phase_kernel(const QArgs a) {
         }
         // gradient of one joint of the evaluation whose arrays start at CBx: subtree wrench of the joint's
         // body = its sites in (body id, site id) order, summed from zero, then the joint formulas
-        auto joint_gradient = [&](const int j, float *CBx) {
+        auto joint_gradient = [&](const int j, float *CBx, float *ggx) {
             const float *swx = CBx + H.c_sw, *jax_ = CBx + H.c_ja, *qsvx = CBx + H.c_qsv, *jnx = CBx + H.c_jn;
-            float *ggx = CBx + H.c_gg;
-            const V3 crefx = ld3(CBx + H.c_bx + 7);
+            const V3 crefx = ld_tpos(CBx + H.c_bx + kXf);
             const float *jr = jrec + 12 * j;
             const int4 ji = lds4i(jr);  // type, qadr, slo, shi
             const int ty = ji.x, ad = ji.y;
@@ -390,8 +407,8 @@ void q_phase_kernel(const QArgs a) {
                     Fs = add3(Fs, ld3(swx + 6 * i));
                     T0 = add3(T0, ld3(swx + 6 * i + 3));
                 }
-                const V3 anchor = ld3(jax_ + 7 * j);
-                const Q4 prequat = ld4(jax_ + 7 * j + 3);
+                const V3 anchor = ld_tpos(jax_ + kXf * j);
+                const Q4 prequat = ld_tquat(jax_ + kXf * j);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
                 if (ty == JHINGE) {
                     const float4 ja4 = lds4(jr + 8);
@@ -432,7 +449,7 @@ void q_phase_kernel(const QArgs a) {
             // ---- per-joint gradient: subtree wrench of the joint's body = its sites in
             //      (body id, site id) order, summed from zero, then the joint formulas ---------------------
             const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
-            for (int j = lg; j < naj_g; j += G) joint_gradient(j, CB);
+            for (int j = lg; j < naj_g; j += G) joint_gradient(j, CB, gg);
             wave_sync();
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -540,45 +557,57 @@ void q_phase_kernel(const QArgs a) {
         }
 
 
-        if (SPEC && __any(st_in == ST_SPEC)) {
+        if (SPEC && __any(st_in == ST_SPEC)) {  // the whole chain is in this state: the solver state is replicated
             // (1) which candidate would the sequential line search take?  Candidate n = nls + c is evaluated
             //     only while n < maxls; candidate n == maxls is taken without evaluation (jaxopt's loop bound).
             const float ec = eta * spec_pow;
             const bool ok = !(ec * (loss - fy) > ec * sum1 + 0.5f * sum0 + eps);  // sufficient decrease (own candidate)
-            const bool take = (st_in == ST_SPEC) && role < 4 && (ok || nls + role >= a.maxls);
-            const unsigned long long bal = __ballot(take);
-            if (bal == 0ull) {  // none of the four: halve four more times
-                if (st_in == ST_SPEC) {
-                    eta = eta * 0.0625f;
-                    nls += 4;
-                    c_ls += 4;
-                }
+            const bool take = role < 4 && (ok || nls + role >= a.maxls);
+            float *xc = XB + trip_parity * 32;
+            if (lg == 0) { xc[4 * role] = take ? 1.0f : 0.0f; xc[4 * role + 1] = loss; }
+            chain_sync();
+            int cs = -1;  // first accepting role = c*
+#pragma unroll
+            for (int c = 3; c >= 0; --c)
+                if (xc[4 * c] != 0.0f) cs = c;
+            if (cs < 0) {  // none of the four: halve four more times
+                eta = eta * 0.0625f;
+                nls += 4;
+                c_ls += 4;
             } else {
-                const int cs = (__ffsll((long long)bal) - 1) >> 3;  // first accepting group = c*
                 const int evaluated = (nls + cs >= a.maxls) ? cs : cs + 1;
                 const float pw = cs == 0 ? 1.0f : cs == 1 ? 0.5f : cs == 2 ? 0.25f : 0.125f;
                 const float eacc = eta * pw;
-                // (2) Only two of the eight evaluations need their gradient: the accepted candidate (group c*, for the
-                //     stopping residual) and the momentum point it leads to (group 4 + c*, the next iteration's grad f).
-                //     All 64 lanes share the 2 naj joints; every group then reads both vectors from LDS.
-                float *CBw = lds + plan_words + a.mb_words + (size_t)(wave * CPW) * H.chain_stride;
+                // (2) Only two of the eight evaluations need their gradient: the accepted candidate (role c*, for the
+                //     stopping residual) and the momentum point it leads to (role 4 + c*, the next iteration's grad f).
+                //     The wave(s) owning them run the joint pass with all 64 lanes; every role then reads both vectors.
+                float *gxa = XB + 64 + trip_parity * 2 * nqpad, *gxn = gxa + nqpad;
                 float *CBa = CBw + cs * H.chain_stride, *CBn = CBw + (4 + cs) * H.chain_stride;
-                for (int e = lane; e < nqpad; e += 64) { (CBa + H.c_gg)[e] = 0.0f; (CBn + H.c_gg)[e] = 0.0f; }
-                wave_sync();
-                for (int i = lane; i < 2 * H.naj; i += 64) {
-                    const bool nx = i >= H.naj;
-                    joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa);
+                if constexpr (NW == 1) {
+                    for (int e = lane; e < nqpad; e += 64) { gxa[e] = 0.0f; gxn[e] = 0.0f; }
+                    wave_sync();
+                    for (int i = lane; i < 2 * H.naj; i += 64) {
+                        const bool nx = i >= H.naj;
+                        joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa, nx ? gxn : gxa);
+                    }
+                } else {
+                    const bool mine_a = cs / CPW == wave, mine_n = (4 + cs) / CPW == wave;  // wave-uniform
+                    if (mine_a || mine_n) {
+                        float *gx = mine_a ? gxa : gxn, *CBx = mine_a ? CBa : CBn;
+                        for (int e = lane; e < nqpad; e += 64) gx[e] = 0.0f;
+                        wave_sync();
+                        for (int j = lane; j < H.naj; j += 64) joint_gradient(j, CBx, gx);
+                    }
                 }
-                wave_sync();
+                chain_sync();
                 float gnext[NQR];
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
                     const bool on = e < nq && ((mbits >> r) & 1u);
-                    gnew[r] = on ? (CBa + H.c_gg)[e] : 0.0f;
-                    gnext[r] = on ? (CBn + H.c_gg)[e] : 0.0f;
+                    gnew[r] = on ? gxa[e] : 0.0f;
+                    gnext[r] = on ? gxn[e] : 0.0f;
                 }
-                wave_sync();
                 float t0[NQR];
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
@@ -591,35 +620,34 @@ void q_phase_kernel(const QArgs a) {
                     }
                     t0[r] = a0;
                 }
-                const float e2 = group_tree_sum<G, NQR>(t0);  // the same value in every group
-                const float fx_c = __shfl(loss, cs * 8, 64);
-                // (3) f at the next momentum point comes from group 4 + c*
-                const float fy_next = __shfl(loss, (4 + cs) * 8, 64);
-                if (st_in == ST_SPEC) {
-                    c_ls += evaluated;
-                    c_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
-                    const float next_step = (eacc <= 1e-6f) ? 1.0f : eacc / 0.5f;
+                const float e2 = group_tree_sum<G, NQR>(t0);  // the same value in every role
+                const float fx_c = xc[4 * cs + 1];
+                // (3) f at the next momentum point comes from role 4 + c*
+                const float fy_next = xc[4 * (4 + cs) + 1];
+                c_ls += evaluated;
+                c_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
+                const float next_step = (eacc <= 1e-6f) ? 1.0f : eacc / 0.5f;
 #pragma unroll
-                    for (int r = 0; r < NQR; ++r) {
-                        const int e = r * G + lg;
-                        const float cr = e < nq ? clipf(FMA(-eacc, g[r], y[r]), lbv[e], ubv[e]) : x[r];
-                        const float d = cr - x[r];
-                        y[r] = FMA(spec_beta, d, cr);
-                        x[r] = cr;
-                        g[r] = gnext[r];
-                    }
-                    fx = fx_c;
-                    error = __builtin_sqrtf(e2);
-                    stepsize = next_step;
-                    t = spec_tn;
-                    iter++;
-                    fy = fy_next;
-                    eta = stepsize;
-                    nls = 0;
-                    if (!(error > a.tol && iter < a.maxiter)) ending = true;
-                    else { c_grad += 1; }  // f, grad f at the next y: already evaluated (group 4 + c*)
+                for (int r = 0; r < NQR; ++r) {
+                    const int e = r * G + lg;
+                    const float cr = e < nq ? clipf(FMA(-eacc, g[r], y[r]), lbv[e], ubv[e]) : x[r];
+                    const float d = cr - x[r];
+                    y[r] = FMA(spec_beta, d, cr);
+                    x[r] = cr;
+                    g[r] = gnext[r];
                 }
+                fx = fx_c;
+                error = __builtin_sqrtf(e2);
+                stepsize = next_step;
+                t = spec_tn;
+                iter++;
+                fy = fy_next;
+                eta = stepsize;
+                nls = 0;
+                if (!(error > a.tol && iter < a.maxiter)) ending = true;
+                else { c_grad += 1; }  // f, grad f at the next y: already evaluated (role 4 + c*)
             }
+            trip_parity ^= 1;
         }
 
         PROF_TICK(8);  // accept / fused residual
@@ -691,10 +719,18 @@ void q_phase_kernel(const QArgs a) {
                             st = ST_DONE;
                             if (a.ctl && !a.resume) {
                                 if (!SPEC && lg == 0) atomicAdd(a.ctl, 1);  // finished chains (hand-off threshold)
-                                if (a.queue_slots > 0) {  // chain queue: take the next unstarted chain (latency mode: the
-                                    int nxt = 0;          // whole wavefront, i.e. all eight groups, moves on together)
-                                    if (SPEC ? lane == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
-                                    nxt = __shfl(nxt, SPEC ? 0 : grp * G, 64);
+                                if (a.queue_slots > 0) {  // chain queue: take the next unstarted chain (latency mode: all
+                                    int nxt = 0;          // eight roles of the chain move on together)
+                                    if constexpr (SPEC && NW > 1) {
+                                        int *xq = reinterpret_cast<int *>(XB + 64 + 4 * nqpad);
+                                        if (threadIdx.x == 0) xq[0] = atomicAdd(a.ctl + 4, 1);
+                                        __syncthreads();
+                                        nxt = xq[0];
+                                        __syncthreads();
+                                    } else {
+                                        if (SPEC ? lane == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
+                                        nxt = __shfl(nxt, SPEC ? 0 : grp * G, 64);
+                                    }
                                     if (nxt < a.C) begin_chain(nxt);
                                 }
                             }
@@ -866,7 +902,9 @@ hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4,
 template <int G, int NQR, int WPE, bool SPEC>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int CPW = SPEC ? 1 : 64 / G;
-    const int per_block = CPW * wpb;
+    constexpr int NW = SPEC ? G / 8 : 1;  // SPEC: wavefronts per chain; more than one -> one chain per workgroup
+    if (NW > 1) wpb = NW;
+    const int per_block = NW > 1 ? 1 : CPW * wpb;
     // a resume launch has one slot per hand-off entry; with a chain queue the grid covers the resident slots only
     const int slots = a.resume ? a.resume_slots : (a.queue_slots > 0 ? std::min(a.queue_slots, a.C) : a.C);
     const int blocks = (slots + per_block - 1) / per_block;
@@ -884,13 +922,14 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     const int nq = a.h.nq;
     *capacity_out = 0;
     if (spec) {
-        if (G != 8) return hipErrorInvalidValue;
-#define STAC_TRY_SPEC(RR)                                            \
-    if (nq <= 8 * RR) {                                              \
-        *capacity_out = 8 * RR;                                      \
-        return launch_q<8, RR, 2, true>(a, wpb, lds_bytes, s);       \
+#define STAC_TRY_SPEC(GG, RR, WW)                                    \
+    if (G == GG && nq <= GG * RR) {                                  \
+        *capacity_out = GG * RR;                                     \
+        return launch_q<GG, RR, WW, true>(a, wpb, lds_bytes, s);     \
     }
-        STAC_TRY_SPEC(10) STAC_TRY_SPEC(16) STAC_TRY_SPEC(32)
+        STAC_TRY_SPEC(8, 10, 2) STAC_TRY_SPEC(8, 16, 2) STAC_TRY_SPEC(8, 32, 2)
+        STAC_TRY_SPEC(32, 3, 2) STAC_TRY_SPEC(32, 8, 2)
+        STAC_TRY_SPEC(64, 2, 2) STAC_TRY_SPEC(64, 4, 2)
 #undef STAC_TRY_SPEC
         return hipErrorInvalidValue;
     }

@@ -109,7 +109,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     uint32_t c_iter = 0, c_ls = 0, c_grad = 0, c_solves = 0;
     float x[NQR], g[NQR], tr[NQR], q0[NQR];
 
-    if (lg == 0) { bx[0] = 0.f; bx[1] = 0.f; bx[2] = 0.f; bx[3] = 1.f; bx[4] = 0.f; bx[5] = 0.f; bx[6] = 0.f; }
+    if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
     size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
 #pragma unroll
     for (int r = 0; r < NQR; ++r) {
@@ -158,15 +158,15 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
 
         PROF_TICK(1);  // stage + FK
         // ---- sites: world position (kept for the Jacobian), residual, loss term, wrench -------------------------------
-        const V3 cref = ld3(bx + 7);
+        const V3 cref = ld_tpos(bx + kXf);
         const bool trunk_w = kind < 2;
         const int Kpad = (K + 3) & ~3;
         for (int k = K + lg; k < Kpad; k += G) r2[k] = 0.0f;
         for (int k = lg; k < K; k += G) {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
-            const float *bp = bx + (ss & 0xFFFF) * 7;
-            const V3 sx = add3(ld3(bp), rotate(V3{sr.x, sr.y, sr.z}, ld4(bp + 3)));
+            const float *bp = bx + (ss & 0xFFFF) * kXf;
+            const V3 sx = add3(ld_tpos(bp), rotate(V3{sr.x, sr.y, sr.z}, ld_tquat(bp)));
             const float w = trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f;
             const float rx = (kpl[3 * k] - sx.x) * w, ry = (kpl[3 * k + 1] - sx.y) * w, rz = (kpl[3 * k + 2] - sx.z) * w;
             const V3 fv = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
@@ -197,13 +197,13 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                 Fs = add3(Fs, ld3(sw + 6 * i));
                 T0 = add3(T0, ld3(sw + 6 * i + 3));
             }
-            const V3 anchor = ld3(ja + 7 * j);
-            const Q4 prequat = ld4(ja + 7 * j + 3);
+            const V3 anchor = ld_tpos(ja + kXf * j);
+            const Q4 prequat = ld_tquat(ja + kXf * j);
             const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
             if (ty == JHINGE || ty == JSLIDE) {
                 const float4 ja4 = lds4(jr + 8);
                 const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, prequat);
-                st3(ja + 7 * j + 3, axis);
+                st3(ja + kXf * j + 4, axis);
                 gg[ad] = ty == JHINGE ? dot3(axis, tau) : dot3(axis, Fs);
             } else if (ty == JFREE) {
                 st3(gg + ad, Fs);
@@ -280,8 +280,8 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                     DofGeom g2;
                     g2.ty = reinterpret_cast<const int *>(jr)[0];
                     g2.comp = dr.z;
-                    g2.anchor = ld3(ja + 7 * dr.y);
-                    g2.axis = ld3(ja + 7 * dr.y + 3);
+                    g2.anchor = ld_tpos(ja + kXf * dr.y);
+                    g2.axis = ld3(ja + kXf * dr.y + 4);
                     g2.qh = Q4{1.f, 0.f, 0.f, 0.f};
                     g2.dn = 1.0f;
                     if (g2.ty == JFREE) {

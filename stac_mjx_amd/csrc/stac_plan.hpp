@@ -13,6 +13,11 @@ constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 // A lane of a G-lane group takes the sites k = r * G + lane, r < kSiteRounds: their keypoints and loss terms stay in
 // registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
 constexpr int kSiteRounds = 3;
+// A transform entry in a chain's LDS region: position in words 0-2 (word 3 unused), quaternion in words 4-7, 16-byte
+// aligned so that it moves with two ds_read_b128 / ds_write_b128 (seven scalar words took four store instructions, and
+// LDS instruction issue, not bandwidth, is what a lone wavefront pays for).  Used for the body transforms (c_bx) and
+// the per-joint {anchor, pre-joint quaternion} entries (c_ja; the pre-pass parks the joint-local quaternion in 4-7).
+constexpr int kXf = 8;
 
 // Records are 16-byte aligned so the kernel fetches them with ds_read_b128.
 struct BodyRec {      // 12 words
@@ -41,25 +46,38 @@ struct JointRec {     // 12 words
 // max(1, most joints of a body in it) micro-levels; a body's first step composes it with its parent and applies
 // its first joint, further joints are further steps.  Fixed-size records at (micro_level * max_width + position)
 // make every address a function of the loop counter, so the kernel fetches step k+1 while it computes step k.
+//
+// Every step runs the SAME straight-line arithmetic, with neutral data where a part does not apply:
+//     pos  = pos + rotate(bpos, quat)          bpos = 0 when the step does not start a body      (exact no-op)
+//     quat = quat * bquat                      only in models with oriented bodies; identity else (exact)
+//     anchor = rotate(jpos, quat) + pos;  prequat = quat
+//     quat = quat * ql                         ql = joint-local quaternion; the identity when the step has no joint
+//     pos  = anchor - rotate(jpos, quat)       jpos = 0: anchor = pos stays (exact)
+// which is a hinge / ball joint or nothing at all.  Free and slide joints and parents that another lane produced are
+// the exceptions; the per-micro-level flag words in front of the records say whether ANY position has one, so the
+// common step has no divergent branch and no select.  All offsets are word offsets into the chain's LDS region.
 struct FkStep {       // 12 words (+4 when some active body has a non-identity body_quat)
-    int32_t flags;    // FK_* bits; 0 = nothing to do at this position
-    int32_t parent;   // transform index of the parent (0 = world)                             [FK_BODY]
-    int32_t j;        // active joint index                                                   [FK_JOINT]
-    int32_t jnext;    // joint index of this position's next step (its ql is fetched one step ahead), else 0
-    float bpos[3];    // body_pos                                                             [FK_BODY]
-    int32_t xf;       // transform index this body is stored at (FK_LAST is only set for stored bodies)
-    float jpos[3];    // jnt_pos                                                              [FK_JOINT]
-    int32_t qadr;     // qpos address                                                         [FK_JOINT]
+    float bpos[3];    // body_pos, or zeros
+    int32_t par_off;  // transform of the parent (c_bx + kXf * index) when another lane produced it, else -1 (the
+                      // lane's running transform is the parent's)
+    float jpos[3];    // jnt_pos, or zeros
+    int32_t ja_off;   // this joint's anchor / pre-joint quaternion entry (c_ja + kXf * j), -1 = no joint in this step
+    int32_t xf_off;   // where the body's transform goes after this step (c_bx + kXf * index), -1 = not stored
+    int32_t ql_next;  // joint-local quaternion of this position's NEXT step (fetched one step ahead), or the
+                      // identity quaternion of the world entry (c_bx + 4)
+    int32_t kind;     // FK_KIND_*
+    int32_t aux;      // free: qpos address; slide: active joint index
     // float bquat[4] follows when PlanHeader::fk_rec_words == 16
 };
+enum : int32_t { FK_KIND_PLAIN = 0, FK_KIND_FREE = 1, FK_KIND_SLIDE = 2 };
+// per-micro-level flags (wave-uniform: every chain of a wavefront runs the same program in lockstep): SOME position ...
 enum : int32_t {
-    FK_BODY = 1,         // compose with the parent: pos = ppos + rotate(body_pos, pquat), quat = pquat * body_quat
-    FK_PARENT_LDS = 2,   // parent transform comes from LDS (else it is still in the lane's registers)
-    FK_BQUAT = 4,        // body_quat is not the identity
-    FK_JOINT = 8,
-    FK_JTYPE_SHIFT = 4,  // bits 4-5: mjtJoint
-    FK_JZERO = 64,       // jnt_pos == 0: rotate(0, q) = 0, anchor = pos (exact)
-    FK_LAST = 128,       // last step of the body: store its transform
+    FK_ML_PARENT_LDS = 1,  // ... starts a body whose parent another lane (or nobody) produced
+    FK_ML_SPECIAL = 2,     // ... has a free or a slide joint
+    FK_ML_BODY = 4,        // ... starts a body (else the compose with body_pos = 0 is skipped: exact)
+    FK_ML_JOINT = 8,       // ... has a joint (else the whole joint part is skipped)
+    FK_ML_JPOS = 16,       // ... has a joint with jnt_pos != 0 (else anchor = pos and pos stays: exact)
+    FK_ML_BQUAT = 32,      // ... starts a body with a non-identity body_quat
 };
 
 struct SiteRec {      // 4 words
@@ -87,8 +105,8 @@ struct PlanHeader {
     int32_t total_words;   // words a launch stages in LDS (the per-launch copy may stop at core_words)
     int32_t core_words;    // blob without the FK program (the program is last)
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
-    int32_t c_bx;      // [(nst+1)*7] pos(3) quat(4) of the stored bodies; entry 0 = world
-    int32_t c_ja;      // [naj*7] anchor(3) + quaternion before the joint(4) (the joint pass rotates the axis)
+    int32_t c_bx;      // [(nst+1)*kXf] transform entries of the stored bodies; entry 0 = world
+    int32_t c_ja;      // [naj*kXf] anchor + quaternion before the joint (the joint pass rotates the axis)
     int32_t c_jn;      // [nqj] |q| of the active free / ball quaternions, by quaternion ordinal (JointRec::q0)
     int32_t c_sw;      // [K*6] site wrench f(3) t(3), by sorted-site position
     int32_t c_gg;      // [nqpad] gradient out: inside c_bx behind the world and root entries when it fits (the body
@@ -103,8 +121,12 @@ struct PlanHeader {
     int32_t nqj;       // active quaternion joints (free / ball)
     int32_t kpow2;     // K rounded up to a power of two (the LDS loss tree of models with more than 64 sites)
     int32_t c_qsv;     // [4*nqj] their normalised quaternions, kept for the gradient pass
-    int32_t off_fkstep;    // FkStep[n_mlev * max_width] (word offset into the blob)
+    int32_t off_fkstep;    // header (fk_hdr_words: one word per PAIR of micro-levels (FK_ML_* of step ml | FK_ML_* of step ml + 1 << 8), then the ql offset of
+                           // each position's first step), then FkStep[n_mlev * max_width] (word offset into the blob)
     int32_t off_fkroot;    // same size: the pruned program of the root passes (filled per call from the trunk keypoints)
+    int32_t fk_hdr_words;  // words in front of the records of either program
+    int32_t n_mlev_hdr;    // micro-levels of the full program: the header holds n_mlev_hdr / 2 flag words, then the
+                           // first-step ql offsets
     int32_t n_mlev;        // micro-levels of the FK program
     int32_t fk_rec_words;  // 12, or 16 when the records carry body_quat
 };
