@@ -699,3 +699,64 @@ def test_m_partial_with_zero_frames(rodent_setup):
     np.testing.assert_array_equal(_np(out), ref)
     np.testing.assert_array_equal(_np(out), m0)
     assert float(err[0]) == rerr == 0.0
+
+
+# ---- latency mode over 1, 4 and 8 wavefronts per chain ---------------------------------------------------------------
+@pytest.mark.parametrize("specg", ["8", "32", "64"])
+def test_latency_mode_wavefronts_per_chain(rodent_setup, fly_setup, mouse_setup, rodent_mocap, monkeypatch, specg):
+    """The eight speculative evaluations of a chain on one wavefront (8 lanes each), on four (32 lanes) or on eight
+    (64 lanes each; roles exchange accept flags, losses and two gradients through LDS, two workgroup barriers per
+    trip): warm-started multi-frame clips of three models, small line-search bound included -- all equal the oracle
+    bit for bit, and each other."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    monkeypatch.setenv("STAC_HIP_SPEC", "1")
+    monkeypatch.setenv("STAC_HIP_SPECG", specg)
+    fs = rodent_setup
+    kp = rodent_mocap[:24].reshape(3, 8, 69)
+    for maxls in (15, 2):
+        eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=60, maxls=maxls)
+        orc = Oracle(fs.tables, tol=1e-4, maxiter=60, maxls=maxls)
+        res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                          root_dims=fs.root_dims, do_root_opt=True)
+        ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+        _compare_phase(res, ref)
+        np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
+    # fruit fly: oriented bodies (16-word FK records), no root optimisation
+    fly = fly_setup
+    engf, orcf = _engine(fly, tol=5e-3, maxiter=40), _oracle(fly, tol=5e-3, maxiter=40)
+    rng = np.random.default_rng(21)
+    qt = fly.tables.qpos0[None] + np.clip(rng.normal(0, 0.15, (6, 43)), -0.3, 0.3).astype(np.float32)
+    qt[:, 3:7] = fly.tables.qpos0[3:7]
+    kpf = np.stack([orcf.fk(q)["site_xpos"].reshape(-1) for q in qt]).reshape(2, 3, 90)
+    kpf = kpf + rng.normal(0, 1e-3, kpf.shape).astype(np.float32)
+    _compare_phase(engf.q_phase(kpf, part_masks=fly.part_masks),
+                   orcf.ik_clips(kpf, fly.lb, fly.ub, fly.part_masks, fly.trunk_kps, 0, 7, do_root_opt=False))
+    # mouse: nq = 230 (four solver registers per lane at 64 lanes), 85 tree levels
+    ms = mouse_setup
+    engm, orcm = _engine(ms, maxiter=12), _oracle(ms, maxiter=12)
+    qm = ms.tables.qpos0[None] + np.clip(rng.normal(0, 0.05, (2, 230)), -0.1, 0.1).astype(np.float32)
+    qm[:, 3:7] = ms.tables.qpos0[3:7]
+    kpm = np.stack([orcm.fk(q)["site_xpos"].reshape(-1) for q in qm]).reshape(2, 1, 102)
+    _compare_phase(engm.q_phase(kpm, part_masks=ms.part_masks, trunk_kps=ms.trunk_kps, root_kp_idx=ms.root_kp_idx,
+                                root_dims=ms.root_dims, do_root_opt=ms.do_root_opt),
+                   orcm.ik_clips(kpm, ms.lb, ms.ub, ms.part_masks, ms.trunk_kps, ms.root_kp_idx, ms.root_dims,
+                                 do_root_opt=ms.do_root_opt))
+
+
+@pytest.mark.parametrize("specg", ["8", "32", "64"])
+def test_latency_mode_chain_queue(rodent_setup, rodent_mocap, monkeypatch, specg):
+    """More clips than chain slots in latency mode (forced: 4 slots for 11 clips): the roles of a finished clip -- one
+    wavefront, or all wavefronts of the workgroup together -- take the next unstarted clip."""
+    monkeypatch.setenv("STAC_HIP_SPEC", "1")
+    monkeypatch.setenv("STAC_HIP_SPECG", specg)
+    monkeypatch.setenv("STAC_HIP_QUEUE", "4")
+    fs = rodent_setup
+    eng, orc = _engine(fs, maxiter=30), _oracle(fs, maxiter=30)
+    kp = rodent_mocap[100:133].reshape(11, 3, 69)
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                      root_dims=fs.root_dims, do_root_opt=True)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    _compare_phase(res, ref)
+    np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
