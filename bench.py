@@ -60,8 +60,76 @@ def cpu_baseline(fs, cfg, kp_host, target_s=15.0):
     n = int(min(C, max(n0, n0 * target_s / max(t0, 1e-3))))
     t = run(n)
     return {"value": n * F / t, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/stac_oracle.c (f32 PG restatement, OpenMP over clips) on the first {n} clips x {F} frames "
-                      f"of the same synthetic batch, {t:.1f} s"}
+            "sample": f"oracle/stac_oracle.c (f32 PG restatement; gcc -O3 -mfma -ffp-contract=off, OpenMP schedule(dynamic) over "
+                      f"clips, {cores} threads) on the first {n} clips x {F} frames of the same synthetic batch, {t:.1f} s"}
+
+
+def run_fit_mode(args, rank, local_rank, world, dist):
+    """--mode fit: Stac.fit_offsets with stac.fit_frames_per_clip (engine extension): the fit frames are cut into clips,
+    the clips are sharded over the ranks (one process per GPU) and every calibration iteration all-reduces the 3K + 2
+    offset-phase sums over RCCL -- the one data-path collective of the engine.  Weak scaling: every rank
+    brings `--frames` frames.  A step = one whole fit (N_ITERS pose passes + offset phases, then the final pose pass)."""
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.stac import Stac
+    from stac_mjx_amd.synth import synth_keypoints, synth_offsets
+
+    fs, mcfg = load_setup("rodent")
+    F = args.frames_per_clip if args.frames_per_clip > 1 else 10
+    C = args.frames // F
+    cfg = validate_config({"model": dict(mcfg), "stac": dict(
+        fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="synthetic", continuous=False, n_fit_frames=world * C * F,
+        skip_fit_offsets=False, skip_ik_only=True, infer_qvels=False, n_frames_per_clip=F, fit_frames_per_clip=F, gather="none",
+        mujoco=dict(solver="newton", iterations=1, ls_iterations=4))})
+    stac = Stac(None, cfg, fs.kp_names, setup=fs, device=f"cuda:{local_rank}", verbose=False)
+    eng = stac.engine
+    gen = Engine(fs.tables, fs.lb, fs.ub, device=f"cuda:{local_rank}")
+    gen.set_site_pos(synth_offsets(fs))  # keypoints come from perturbed offsets: the fit has something to find
+    fk = lambda q: gen.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
+    kp_host, _ = synth_keypoints(fs, fk, world * C, F, seed=3, noise_seed=4)  # the same global batch on every rank
+    kp = kp_host.reshape(world * C * F, -1)
+    n_pass = int(mcfg["N_ITERS"]) + 1
+    off0 = fs.tables.site_pos.copy()
+
+    def step():
+        eng.set_site_pos(off0)
+        return stac.fit_offsets(kp)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        data = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    solves = world * C * F * n_pass * args.steps
+    d_off = float(np.linalg.norm(data.offsets - synth_offsets(fs), axis=-1).mean() * 1e3)
+    line = {
+        "metric": "frame-solves/sec STAC fit_offsets (rodent, 23 kp), clip-parallel calibration",
+        "value": solves / elapsed, "unit": "frame-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"Stac.fit_offsets, stac.fit_frames_per_clip={F}: {C * F} frames per GPU as {C} clips, N_ITERS={n_pass - 1} "
+                        f"(+ final pass), PG parity mode; NOT the reference's single-chain sequencing (engine extension)",
+            "frames_per_gpu": C * F, "fit_frames_per_clip": F,
+            "parallelism": f"clips sharded over {world} GPU(s); offset phase: one all-reduce of {3 * fs.tables.nsite + 2} floats per "
+                           f"calibration iteration ({n_pass - 1} per fit)",
+            "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
+            "mean_offset_error_mm_vs_generating_offsets": d_off,
+        },
+    }
+    if rank == 0:
+        print(json.dumps(line))
 
 
 def main():
@@ -73,6 +141,10 @@ def main():
     ap.add_argument("--frames-per-clip", type=int, default=1)
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the clips250 and LM legs (profiling runs)")
+    ap.add_argument("--mode", default="ik", choices=["ik", "fit"],
+                    help="ik = q_phase only (the BASELINE metric); fit = offset/pose alternation on clips sharded over the "
+                         "ranks with the offset-phase all-reduce over RCCL (stac.fit_frames_per_clip), reported as frame-solves/s")
     ap.add_argument("--solver", default="pg", choices=["pg", "lm"],
                     help="pg = the reference's projected gradient (parity mode, the BASELINE metric); lm = optional fast solver")
     ap.add_argument("--model", default="rodent", choices=["rodent", "fly", "mouse"],
@@ -92,6 +164,12 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    if args.mode == "fit":
+        run_fit_mode(args, rank, local_rank, world, dist)
+        if dist:
+            dist.destroy_process_group()
+        return
 
     from stac_mjx_amd.engine import Engine
     from stac_mjx_amd.synth import synth_keypoints, synth_offsets
@@ -176,7 +254,51 @@ def main():
                      "algorithmic_bytes_per_launch": frames_step * bytes_frame,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": bytes_frame},
     }
-    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent":
+    # VALU view of the same launch (the binding resource; informative next to the required HBM roofline): issued VALU
+    # wave-instructions per step from the committed rocprofv3 PMC pass of this workload (profiles/), against the
+    # algorithmic work of the evaluations the kernel's own counters report
+    try:
+        for ent in json.load(open(ROOT / "profiles" / "valu.json"))["entries"]:
+            if ent["frames"] == frames_step and ent["frames_per_clip"] == F and args.model == ent.get("model", "rodent") and args.solver == "pg":
+                evals = float(cnt[1] + cnt[2])  # logical q_loss evaluations of the step (line-search + value-and-gradient)
+                lane_slots = ent["sq_insts_valu"] * 64.0
+                line["roofline_valu"] = {
+                    "sq_insts_valu_per_step": ent["sq_insts_valu"], "source": ent["source"],
+                    "logical_evaluations_per_step": evals, "lane_slots_per_evaluation": lane_slots / evals,
+                    "algorithmic_flops_per_step": flops, "algorithmic_flop_per_lane_slot": flops / lane_slots,
+                    "useful_lane_fraction": (flops / 2.0) / lane_slots,  # one FMA = 2 flop per lane-slot at best
+                    "valu_issue_busy_frac": ent["sq_insts_valu"] * 2.0 / (1024 * 2.4e9 * kern_ms * 1e-3),
+                    "note": "wave64 VALU instruction = 2 issue cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz; busy = issued / available"}
+    except Exception:
+        pass
+    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and F == 1 and not args.no_extras:
+        # BASELINE configs[1] with the reference's DEFAULT chaining (configs/stac/stac.yaml:9, n_frames_per_clip = 250):
+        # the same number of frames as 40 warm-started clips -- latency mode, one chain per workgroup.  Never `value`.
+        Fc = 250
+        Cc = max(frames_step // Fc, 1)
+        kpc_host, _ = synth_keypoints(fs, fk, Cc, Fc, seed=7, noise_seed=8)
+        kpc = torch.as_tensor(kpc_host).to(eng.device)
+        oc = None
+        cev = []
+        for i in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            oc = eng.q_phase(kpc, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                             root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, out=oc)
+            e1.record()
+            cev.append((e0, e1))
+        torch.cuda.synchronize()
+        c_ms = float(cev[1][0].elapsed_time(cev[1][1]))
+        ccnt = oc["counters"].to(torch.float64).sum(dim=(0, 1)).cpu().numpy()
+        cerr = torch.linalg.norm((eng.fk(oc["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
+                                  - kpc.reshape(-1, fs.tables.nsite, 3)), dim=-1)
+        line["config"]["clips250"] = {
+            "workload": f"{Cc * Fc} frames as {Cc} warm-started clips of {Fc} frames (reference default n_frames_per_clip)",
+            "frames_per_s": Cc * Fc / (c_ms * 1e-3), "kernel_ms": c_ms,
+            "iters_per_frame": ccnt[0] / (Cc * Fc), "us_per_pg_iteration": c_ms * 1e3 / (ccnt[0] / Cc),
+            "marker_rmse_mm": float(torch.sqrt((cerr ** 2).mean()).item() * 1e3),
+            "note": "each clip is one serial chain of 250 x ~410 PG iterations: speculative latency mode, 8 wavefronts per chain"}
+    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and not args.no_extras:
         # the north star words the q_phase as a Levenberg-Marquardt update; the reference runs projected gradient (the
         # `value` above, parity mode).  The optional LM solver on the same resident batch, for the record -- never `value`.
         lm = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), device=f"cuda:{local_rank}",

@@ -291,3 +291,54 @@ def test_ik_only_continuous_clips_and_edge_effects(rodent_setup, rodent_cfg, rod
                 np.testing.assert_allclose(o[c * n + f], want, rtol=1e-6, atol=1e-7)
     # the stitched keypoints are the input again wherever both windows saw the same frames (the fade of equal values)
     np.testing.assert_allclose(out.kp_data, kp, rtol=1e-6, atol=1e-7)
+
+
+def _nccl_fit_worker(rank, port, tmp, kp, fpc):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device(f"cuda:{rank}"))
+    try:
+        import json
+
+        from conftest import GOLDEN as G
+        from stac_mjx_amd.fit_model import finish_fit_setup
+        from stac_mjx_amd.mjcf import ModelTables
+        from stac_mjx_amd.stac import Stac
+
+        mcfg = json.load(open(G / "rodent_model_cfg.json"))
+        fs = finish_fit_setup(ModelTables.load(G / "rodent_tables.npz"), mcfg, list(mcfg["KEYPOINT_MODEL_PAIRS"].keys()))
+        cfg = _cfg(mcfg, fit_frames_per_clip=fpc, n_frames_per_clip=fpc)
+        cfg.model.N_ITERS = 2
+        stac = Stac(None, cfg, fs.kp_names, setup=fs, device=f"cuda:{rank}", verbose=False)
+        data = stac.fit_offsets(kp)
+        ik = stac.ik_only(kp, data.offsets)
+        np.savez(f"{tmp}/nccl{rank}.npz", offsets=data.offsets, qpos=data.qpos, ik_qpos=ik.qpos)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per GPU")
+def test_fit_and_ik_two_ranks_over_rccl(tmp_path, rodent_setup, rodent_cfg, rodent_mocap):
+    """The product path on two GPUs: one process per GPU, backend "nccl" (= RCCL), the 71-float offset-phase sums
+    combined on the device over xGMI, clips sharded, results gathered to rank 0.  Same answers as one process (the
+    fixed-order sum associates differently from the single-process sum: 1e-5 on the offsets)."""
+    import torch.multiprocessing as mp
+
+    from stac_mjx_amd.stac import Stac
+
+    kp = rodent_mocap[300:312]
+    cfg = _cfg(rodent_cfg, fit_frames_per_clip=2, n_frames_per_clip=2)
+    cfg.model.N_ITERS = 2
+    one_stac = Stac(None, cfg, rodent_setup.kp_names, setup=rodent_setup, verbose=False)
+    one = one_stac.fit_offsets(kp)
+    port = 29700 + int(torch.randint(0, 200, (1,)).item())
+    mp.spawn(_nccl_fit_worker, args=(port, str(tmp_path), kp, 2), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "nccl0.npz"), np.load(tmp_path / "nccl1.npz")
+    np.testing.assert_array_equal(r0["offsets"], r1["offsets"])
+    assert r0["qpos"].shape == (12, 74) and r1["qpos"].shape == (6, 74) and r0["ik_qpos"].shape == (12, 74)
+    assert np.abs(r0["offsets"] - one.offsets).max() < 1e-5
+    np.testing.assert_array_equal(r0["qpos"][6:], r1["qpos"])
