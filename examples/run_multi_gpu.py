@@ -14,8 +14,8 @@ What runs (BASELINE.json configs[3], scaled by the arguments):
   2. ``ik_only`` of a long synthetic recording: contiguous blocks of clips per rank, no communication; the results
      are gathered to rank 0 (``stac.gather = rank0``), which writes the output file.
 
-The process group is created with ``device_id`` BEFORE anything touches the GPU.  Data: the committed 1000-frame
-rodent mocap fixture for the fit, synthetic motion for the long ik_only (no dataset can be fetched here).
+The process group is created with ``device_id`` BEFORE anything touches the GPU.  Data: synthetic motion
+(stac_mjx_amd/synth.py; no dataset can be fetched here), 1 mm keypoint noise, marker offsets perturbed by 2 mm.
 """
 
 import argparse
@@ -59,7 +59,6 @@ def main():
     from stac_mjx_amd.fit_model import finish_fit_setup
     from stac_mjx_amd.main import run_stac
     from stac_mjx_amd.mjcf import ModelTables
-    from stac_mjx_amd.stac import Stac
     from stac_mjx_amd.synth import synth_keypoints
 
     g = ROOT / "tests" / "golden"
@@ -72,19 +71,18 @@ def main():
         out_dir.mkdir(parents=True, exist_ok=True)
     dist.barrier()
 
-    # ---- 1. calibration: clips sharded over ranks, one collective per iteration ------------------------------------
-    fit_kp = np.load(g / "rodent_mocap_1000.npy")[: args.fit_frames]
-    # a long recording consistent with the reference offsets: every rank generates the same one (seeded)
-    gen = Stac(None, validate_config({"model": dict(mcfg), "stac": dict(
-        fit_offsets_path="f.h5", ik_only_path="i.h5", data_path="-", continuous=False, n_fit_frames=1, skip_fit_offsets=True,
-        skip_ik_only=True, infer_qvels=False, n_frames_per_clip=1, mujoco=dict(solver="newton", iterations=1, ls_iterations=4))}),
-        kp_names, setup=fs, device=f"cuda:{local_rank}", verbose=False)
-    fk = lambda q: gen.engine.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
-    C = args.ik_frames // args.frames_per_clip
-    ik_kp, _ = synth_keypoints(fs, fk, C, args.frames_per_clip, seed=7, noise_seed=8)
-    ik_kp = ik_kp.reshape(-1, ik_kp.shape[-1])
-    kp_all = np.concatenate([fit_kp, ik_kp], axis=0)  # run_stac fits the first n_fit_frames and tracks everything
-    kp_all = kp_all[: (len(kp_all) // args.frames_per_clip) * args.frames_per_clip]
+    # ---- data: one synthetic recording (seeded: the same on every rank), generated with perturbed marker offsets that
+    #      the calibration has to find; run_stac fits the first n_fit_frames and then tracks everything ------------------
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.synth import synth_offsets
+
+    gen = Engine(fs.tables, fs.lb, fs.ub, device=f"cuda:{local_rank}")
+    gen.set_site_pos(synth_offsets(fs))
+    fk = lambda q: gen.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
+    C = (args.fit_frames + args.ik_frames + args.frames_per_clip - 1) // args.frames_per_clip
+    kp_all, _ = synth_keypoints(fs, fk, C, args.frames_per_clip, seed=7, noise_seed=8)
+    kp_all = kp_all.reshape(-1, kp_all.shape[-1])
+    gen.close()
 
     cfg = validate_config({"model": dict(mcfg), "stac": dict(
         fit_offsets_path="fit_offsets.h5", ik_only_path="ik_only.h5", data_path="-", continuous=False,
