@@ -483,3 +483,61 @@ def test_run_stac_rebinds_the_config_stored_with_the_fit(tmp_path, rodent_setup,
     assert seen["stac"].cfg is caller_cfg                       # the Stac object keeps the caller's config
     assert saved_cfg.stac.infer_qvels is True and saved_cfg.stac.n_frames_per_clip == 2   # the file records the fit's
     assert ik.qvel.shape == (8, 73)                             # and the fit's infer_qvels = True was applied
+
+
+# ---- the .h5 output contract, executed (stac_mjx/io.py:194-278) -------------------------------------------------------
+_H5_PY = "/opt/conda/bin/python3.9"  # this image's interpreter that has h5py (python3.10 has none)
+_H5_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, h5py
+from stac_mjx_amd import io
+from stac_mjx_amd.config import validate_config
+assert io.h5py is not None
+mcfg = json.load(open(sys.argv[1] + "/tests/golden/rodent_model_cfg.json"))
+cfg = validate_config({"model": mcfg, "stac": dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat",
+    continuous=False, n_fit_frames=3, skip_fit_offsets=False, skip_ik_only=False, infer_qvels=True, n_frames_per_clip=3,
+    mujoco=dict(solver="newton", iterations=1, ls_iterations=4))})
+rng = np.random.default_rng(0)
+f32 = lambda *s: rng.normal(size=s).astype(np.float32)
+names = dict(kp_names=list(mcfg["KEYPOINT_MODEL_PAIRS"].keys()), names_qpos=["root"] * 7 + ["j%d" % i for i in range(67)],
+             names_xpos=["b%d" % i for i in range(67)])
+data = dict(kp_data=f32(3, 69), marker_sites=f32(3, 23, 3), offsets=f32(23, 3), qpos=f32(3, 74), xpos=f32(3, 67, 3),
+            xquat=f32(3, 67, 4))
+out = {}
+for tag, qvel in (("fit", np.array([])), ("ik", f32(3, 73))):
+    path = io.save_data_to_h5(config=cfg, file_path=sys.argv[2] + "/" + tag + ".h5", qvel=qvel, **names, **data)
+    assert str(path).endswith(".h5") and io.resolve_output_path(path) == path
+    with h5py.File(path, "r") as f:
+        out[tag] = {k: [str(f[k].dtype), list(f[k].shape), f[k].compression] for k in f.keys()}
+        cfg_yaml = f["config"][()].decode("utf-8")
+    cfg2, back = io.load_stac_data(path)
+    assert cfg2.stac.n_frames_per_clip == 3 and cfg2.model.N_ITERS == cfg.model.N_ITERS and "MJCF_PATH" in cfg_yaml
+    for k, v in data.items():
+        assert np.array_equal(getattr(back, k), v), k
+    assert back.kp_names == names["kp_names"] and back.names_qpos == names["names_qpos"] and back.names_xpos == names["names_xpos"]
+    assert np.array_equal(back.qvel, qvel)
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(_H5_PY), reason="no interpreter with h5py in this image")
+def test_h5_writer_and_reader_executed_with_h5py(tmp_path):
+    """N1: the h5py branch of io.save_data_to_h5 / load_stac_data really runs (under the image's python3.9, which has
+    h5py 3.3): dataset names, string dtypes and gzip compression are the reference's (io.py:224-236), and the file
+    round-trips, also with the empty qvel a fit_offsets file carries."""
+    import subprocess
+
+    r = subprocess.run([_H5_PY, "-c", _H5_SCRIPT, str(ROOT), str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = __import__("json").loads(r.stdout.strip().splitlines()[-1])
+    want = {"config", "kp_names", "names_qpos", "names_xpos", "kp_data", "marker_sites", "offsets", "qpos", "qvel", "xpos", "xquat"}
+    for tag in ("fit", "ik"):
+        d = out[tag]
+        assert set(d) == want, set(d) ^ want
+        assert d["config"][0].startswith("|S") and d["config"][1] == []          # np.bytes_ scalar holding the YAML
+        for k in ("kp_names", "names_qpos", "names_xpos"):
+            assert d[k][0].startswith("|S") and len(d[k][1]) == 1               # fixed-width byte strings
+        for k in ("kp_data", "marker_sites", "offsets", "qpos", "xpos", "xquat"):
+            assert d[k][0] == "float32" and d[k][2] == "gzip", (k, d[k])
+    assert out["ik"]["qvel"] == ["float32", [3, 73], "gzip"] and out["fit"]["qvel"][1] == [0]
