@@ -384,13 +384,31 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         }
         for (int i = 0; i < 4; ++i) r.quat[i] = q[i];
     }
+    // distinct site ranges, longest first (the lanes of a round then run loops of similar length)
+    std::vector<RangeRec> ranges;
+    std::vector<int> aj_rid(naj, 0);
+    {
+        std::vector<std::pair<int, int>> uniq;
+        for (int j = 0; j < naj; ++j) {
+            const std::pair<int, int> r{aj_slo[j], aj_shi[j]};
+            if (std::find(uniq.begin(), uniq.end(), r) == uniq.end()) uniq.push_back(r);
+        }
+        std::stable_sort(uniq.begin(), uniq.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+            return a.second - a.first > b.second - b.first;
+        });
+        for (const auto &r : uniq) ranges.push_back(RangeRec{r.first, r.second});
+        for (int j = 0; j < naj; ++j)
+            aj_rid[j] = (int)(std::find(uniq.begin(), uniq.end(), std::pair<int, int>{aj_slo[j], aj_shi[j]}) - uniq.begin());
+        if (ranges.empty()) ranges.push_back(RangeRec{0, 0});
+    }
+    h.nrange = (int)ranges.size();
     std::vector<JointRec> jrec(std::max(naj, 1));
     int nqj = 0;
     for (int j = 0; j < naj; ++j) {
         JointRec &r = jrec[j];
         r.type = aj_type[j]; r.qadr = aj_qadr[j]; r.slo = aj_slo[j]; r.shi = aj_shi[j];
         for (int i = 0; i < 3; ++i) { r.pos[i] = aj_pos[3 * j + i]; r.axis[i] = aj_axis[3 * j + i]; }
-        r.q0 = aj_q0[j]; r.slot = aj_slot[j];
+        r.q0 = aj_q0[j]; r.rid = aj_rid[j];
         if (aj_type[j] == STAC_JNT_FREE || aj_type[j] == STAC_JNT_BALL) {  // no reference angle: the ordinal among the
             const int32_t qi = nqj++;                                       // quaternion joints (saved-quaternion slot)
             std::memcpy(&r.q0, &qi, 4);
@@ -405,6 +423,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.off_body = put_raw(brec.data(), brec.size() * sizeof(BodyRec) / 4);
     h.off_joint = put_raw(jrec.data(), jrec.size() * sizeof(JointRec) / 4);
     h.off_site = put_raw(srec.data(), srec.size() * sizeof(SiteRec) / 4);
+    h.off_range = put_raw(ranges.data(), ranges.size() * sizeof(RangeRec) / 4);
     h.off_lb = put_fpad(t->lb, nq, h.nqpad);
     h.off_ub = put_fpad(t->ub, nq, h.nqpad);
     h.off_qpos0 = put_fpad(t->qpos0, nq, h.nqpad);
@@ -420,17 +439,18 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.c_jn = o; o += std::max(nqj, 1);
     h.c_qsv = o; o += 4 * nqj;
     o = (o + 3) & ~3;
-    h.c_sw = o; o += std::max(K * 6, h.nqpad);
+    h.c_sw = o; o += std::max(K * kXf, h.nqpad);
     o = (o + 3) & ~3;
     h.kpow2 = 1;
     while (h.kpow2 < K) h.kpow2 <<= 1;
-    // The gradient vector lives inside the body-transform array, behind the world entry and the root's (the joint pass
-    // reads the root position): the transforms are dead once the site pass is over.  Own region if it does not fit.
-    if ((nst + 1) * kXf - 2 * kXf >= h.nqpad) {
-        h.c_gg = h.c_bx + 2 * kXf;
+    // Joint pass: (A) the distinct range sums read the site wrenches and go where the body transforms were (dead once the
+    // site pass is over; the root position the moments refer to is read before); (B) the joints read those sums and write
+    // the gradient where the site wrenches were.  Own region for the sums if they do not fit.
+    h.c_gg = h.c_sw;
+    if ((nst + 1) * kXf >= h.nrange * kXf) {
+        h.c_rw = h.c_bx;
     } else {
-        h.c_gg = o; o += h.nqpad;
-        o = (o + 3) & ~3;
+        h.c_rw = o; o += h.nrange * kXf;
     }
     h.c_qe = h.c_sw;  // the evaluation point is dead once the site pass writes the wrenches (the LM kernel, which reads it
                       // later in the trip, moves it into its own region)

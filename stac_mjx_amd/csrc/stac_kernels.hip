@@ -263,6 +263,8 @@ void q_phase_kernel(const QArgs a) {
         const float spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
         const float spec_beta = (t - 1.0f) / spec_tn;
 
+        // the world entry of the transform array (the gradient pass of the previous trip left its range sums there)
+        if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
@@ -321,8 +323,8 @@ void q_phase_kernel(const QArgs a) {
                 V3 tq = cross3(sub3(sx, cref), f);
                 if (wz) tq = V3{0.0f, 0.0f, 0.0f};
                 const int sp = ss >> 16;
-                st3(sw + 6 * sp, f);
-                st3(sw + 6 * sp + 3, tq);
+                st_tpos(sw + kXf * sp, f);
+                st_tpos(sw + kXf * sp + 4, tq);
             }
             return FMA(rz, rz, FMA(ry, ry, rx * rx));
         };
@@ -386,35 +388,44 @@ void q_phase_kernel(const QArgs a) {
         wave_sync();
         PROF_TICK(4);  // loss sum
         }
-        // gradient of one joint of the evaluation whose arrays start at CBx: subtree wrench of the joint's
-        // body = its sites in (body id, site id) order, summed from zero, then the joint formulas
-        auto joint_gradient = [&](const int j, float *CBx, float *ggx) {
-            const float *swx = CBx + H.c_sw, *jax_ = CBx + H.c_ja, *qsvx = CBx + H.c_qsv, *jnx = CBx + H.c_jn;
-            const V3 crefx = ld_tpos(CBx + H.c_bx + kXf);
+        // ---- gradient pass, two steps over the evaluation whose arrays start at CBx ------------------------
+        // (A) subtree wrench of every DISTINCT site range: the site wrenches in (body id, site id) order, summed left to
+        //     right from zero (RangeRec, stac_plan.hpp); written where the body transforms were
+        const RangeRec *rrec = reinterpret_cast<const RangeRec *>(P + H.off_range);
+        auto range_sum = [&](const int r, float *CBx) {
+            const float *swx = CBx + H.c_sw;
+            const RangeRec rr = rrec[r];
+            V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
+            int i = rr.lo;
+            for (; i + 4 <= rr.hi; i += 4) {  // same left-to-right order; four wrenches in flight per LDS round trip
+                V3 f4[4], t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { f4[u] = ld_tpos(swx + kXf * (i + u)); t4[u] = ld_tpos(swx + kXf * (i + u) + 4); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { Fs = add3(Fs, f4[u]); T0 = add3(T0, t4[u]); }
+            }
+            for (; i < rr.hi; ++i) {
+                Fs = add3(Fs, ld_tpos(swx + kXf * i));
+                T0 = add3(T0, ld_tpos(swx + kXf * i + 4));
+            }
+            st_tpos(CBx + H.c_rw + kXf * r, Fs);
+            st_tpos(CBx + H.c_rw + kXf * r + 4, T0);
+        };
+        // (B) one joint: its range's wrench, then the joint formulas; crefx = the root position the moments refer to
+        auto joint_gradient = [&](const int j, float *CBx, const V3 crefx, float *ggx) {
+            const float *jax_ = CBx + H.c_ja, *qsvx = CBx + H.c_qsv, *jnx = CBx + H.c_jn;
             const float *jr = jrec + 12 * j;
             const int4 ji = lds4i(jr);  // type, qadr, slo, shi
             const int ty = ji.x, ad = ji.y;
-            V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
-                int i = ji.z;
-                for (; i + 4 <= ji.w; i += 4) {  // same left-to-right order; four wrenches in flight per LDS round trip
-                    V3 f4[4], t4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { f4[u] = ld3(swx + 6 * (i + u)); t4[u] = ld3(swx + 6 * (i + u) + 3); }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { Fs = add3(Fs, f4[u]); T0 = add3(T0, t4[u]); }
-                }
-                for (; i < ji.w; ++i) {
-                    Fs = add3(Fs, ld3(swx + 6 * i));
-                    T0 = add3(T0, ld3(swx + 6 * i + 3));
-                }
+            const float4 ja4 = lds4(jr + 8);  // axis, range id
+            const float *rw = CBx + H.c_rw + kXf * __builtin_bit_cast(int, ja4.w);
+            const V3 Fs = ld_tpos(rw), T0 = ld_tpos(rw + 4);
                 const V3 anchor = ld_tpos(jax_ + kXf * j);
                 const Q4 prequat = ld_tquat(jax_ + kXf * j);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
                 if (ty == JHINGE) {
-                    const float4 ja4 = lds4(jr + 8);
                     ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
                 } else if (ty == JSLIDE) {
-                    const float4 ja4 = lds4(jr + 8);
                     ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), Fs);
                 } else {
                     int qa = ad;
@@ -442,14 +453,15 @@ void q_phase_kernel(const QArgs a) {
         for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
         // (latency mode: a speculative trip computes gradients only for the two evaluations it ends up using, below)
         if (any_grad && !(SPEC && st_in == ST_SPEC)) {
-            // gg may sit inside bx (PlanHeader::c_gg): the site pass, the last reader of the transforms, is over
+            // the range sums go where the body transforms were (the site pass, their last reader, is over; cref is in a
+            // register), the gradient where the site wrenches were (dead once the range sums are done)
+            for (int r = lg; r < H.nrange; r += G) range_sum(r, CB);
+            wave_sync();
             for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
             wave_sync();
-            PROF_TICK(5);  // zero gg
-            // ---- per-joint gradient: subtree wrench of the joint's body = its sites in
-            //      (body id, site id) order, summed from zero, then the joint formulas ---------------------
+            PROF_TICK(5);  // range sums + zero gg
             const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
-            for (int j = lg; j < naj_g; j += G) joint_gradient(j, CB, gg);
+            for (int j = lg; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
             wave_sync();
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -584,19 +596,26 @@ void q_phase_kernel(const QArgs a) {
                 float *gxa = XB + 64 + trip_parity * 2 * nqpad, *gxn = gxa + nqpad;
                 float *CBa = CBw + cs * H.chain_stride, *CBn = CBw + (4 + cs) * H.chain_stride;
                 if constexpr (NW == 1) {
+                    const V3 crefa = ld_tpos(CBa + H.c_bx + kXf), crefn = ld_tpos(CBn + H.c_bx + kXf);
                     for (int e = lane; e < nqpad; e += 64) { gxa[e] = 0.0f; gxn[e] = 0.0f; }
+                    for (int i = lane; i < 2 * H.nrange; i += 64) {
+                        const bool nx = i >= H.nrange;
+                        range_sum(nx ? i - H.nrange : i, nx ? CBn : CBa);
+                    }
                     wave_sync();
                     for (int i = lane; i < 2 * H.naj; i += 64) {
                         const bool nx = i >= H.naj;
-                        joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa, nx ? gxn : gxa);
+                        joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa, nx ? crefn : crefa, nx ? gxn : gxa);
                     }
                 } else {
                     const bool mine_a = cs / CPW == wave, mine_n = (4 + cs) / CPW == wave;  // wave-uniform
                     if (mine_a || mine_n) {
                         float *gx = mine_a ? gxa : gxn, *CBx = mine_a ? CBa : CBn;
+                        const V3 crefx = ld_tpos(CBx + H.c_bx + kXf);
                         for (int e = lane; e < nqpad; e += 64) gx[e] = 0.0f;
+                        for (int r = lane; r < H.nrange; r += 64) range_sum(r, CBx);
                         wave_sync();
-                        for (int j = lane; j < H.naj; j += 64) joint_gradient(j, CBx, gx);
+                        for (int j = lane; j < H.naj; j += 64) joint_gradient(j, CBx, crefx, gx);
                     }
                 }
                 chain_sync();

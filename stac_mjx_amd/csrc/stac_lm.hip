@@ -171,8 +171,8 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             const float rx = (kpl[3 * k] - sx.x) * w, ry = (kpl[3 * k + 1] - sx.y) * w, rz = (kpl[3 * k + 2] - sx.z) * w;
             const V3 fv = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
             const int sp = ss >> 16;
-            st3(sw + 6 * sp, fv);
-            st3(sw + 6 * sp + 3, cross3(sub3(sx, cref), fv));
+            st_tpos(sw + kXf * sp, fv);
+            st3(sw + kXf * sp + 4, cross3(sub3(sx, cref), fv));
             st3(sxs + 3 * sp, sx);
             r2[k] = FMA(rz, rz, FMA(ry, ry, rx * rx));
         }
@@ -194,8 +194,8 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             const int ty = ji.x, ad = ji.y;
             V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
             for (int i = ji.z; i < ji.w; ++i) {
-                Fs = add3(Fs, ld3(sw + 6 * i));
-                T0 = add3(T0, ld3(sw + 6 * i + 3));
+                Fs = add3(Fs, ld_tpos(sw + kXf * i));
+                T0 = add3(T0, ld3(sw + kXf * i + 4));
             }
             const V3 anchor = ld_tpos(ja + kXf * j);
             const Q4 prequat = ld_tquat(ja + kXf * j);

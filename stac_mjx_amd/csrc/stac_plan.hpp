@@ -40,8 +40,13 @@ struct JointRec {     // 12 words
     float pos[3];
     float q0;         // qpos0[qadr] (hinge / slide reference); free / ball: int32 ordinal among the quaternion joints
     float axis[3];
-    int32_t slot;     // body slot
+    int32_t rid;      // index of the joint's site range among the DISTINCT subtree ranges (RangeRec)
 };
+// The subtree wrench a joint needs is the sum, left to right from zero, of the site wrenches at the sorted-site
+// positions [lo, hi) of its body's subtree.  Joints on one body, and bodies that carry no site of their own above a
+// single child, share their range (rodent: 39 joints, 19 distinct ranges; mouse: 181 joints, 27), so every distinct
+// range is summed ONCE -- longest first -- and the joints read the result.
+struct RangeRec { int32_t lo, hi; };
 // One step of the FK "program": the work of one lane position in one micro-level.  A level of the tree takes
 // max(1, most joints of a body in it) micro-levels; a body's first step composes it with its parent and applies
 // its first joint, further joints are further steps.  Fixed-size records at (micro_level * max_width + position)
@@ -108,9 +113,11 @@ struct PlanHeader {
     int32_t c_bx;      // [(nst+1)*kXf] transform entries of the stored bodies; entry 0 = world
     int32_t c_ja;      // [naj*kXf] anchor + quaternion before the joint (the joint pass rotates the axis)
     int32_t c_jn;      // [nqj] |q| of the active free / ball quaternions, by quaternion ordinal (JointRec::q0)
-    int32_t c_sw;      // [K*6] site wrench f(3) t(3), by sorted-site position
-    int32_t c_gg;      // [nqpad] gradient out: inside c_bx behind the world and root entries when it fits (the body
-                       // transforms are dead once the sites have read them; the joint pass only reads the root position)
+    int32_t c_sw;      // [K*kXf] site wrench entries {f(3), -, t(3), -} by sorted-site position
+    int32_t c_gg;      // [nqpad] gradient out: the site-wrench region (dead once the range sums are done)
+    int32_t c_rw;      // [nrange*kXf] wrench sums of the distinct ranges {F(3), -, T(3), -}: the body-transform region
+                       // when they fit (the transforms are dead once the sites have read them), else an own region
+    int32_t nrange, off_range;  // RangeRec[nrange] in the blob
     int32_t c_qe;      // [nqpad] evaluation point (quaternions normalised in place); aliases c_sw in the PG kernel
     int32_t c_kp;      // [3K] keypoints of the current frame      } only when a lane group has more than kSiteRounds
     int32_t c_r2;      // [K padded] per-site loss terms           } sites per lane: else both stay in registers
