@@ -13,11 +13,12 @@ f=$(find /tmp/rp_${tag}_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
+           "SQ_INSTS_BRANCH SQ_ACTIVE_INST_ANY SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAVE_CYCLES SQ_WAVES" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf /tmp/rp_${tag}_$i
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/rp_${tag}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /tmp/rp_${tag}_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/rp_${tag}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /tmp/rp_${tag}_$i.log 2>&1
   python3 $R/profiles/tools/pmc_summary.py /tmp/rp_${tag}_$i q_phase > $OUT/pmc_pass$i.json
 done
 tail -1 $OUT/bench.json | cut -c1-200
