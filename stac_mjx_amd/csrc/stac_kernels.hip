@@ -577,7 +577,9 @@ void q_phase_kernel(const QArgs a) {
             const bool take = role < 4 && (ok || nls + role >= a.maxls);
             float *xc = XB + trip_parity * 32;
             if (lg == 0) { xc[4 * role] = take ? 1.0f : 0.0f; xc[4 * role + 1] = loss; }
+            PROF_TICK(8);
             chain_sync();
+            PROF_TICK(4);  // latency mode: wait for the other roles' losses
             int cs = -1;  // first accepting role = c*
 #pragma unroll
             for (int c = 3; c >= 0; --c)
@@ -618,7 +620,9 @@ void q_phase_kernel(const QArgs a) {
                         for (int j = lane; j < H.naj; j += 64) joint_gradient(j, CBx, crefx, gx);
                     }
                 }
+                PROF_TICK(5);  // latency mode: gradient pass of the two chosen evaluations (owner waves)
                 chain_sync();
+                PROF_TICK(6);  // latency mode: wait for the gradients
                 float gnext[NQR];
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
