@@ -1,7 +1,8 @@
 """CPU oracle for the STAC hot path -- TEST INFRASTRUCTURE ONLY.
 
 ctypes front-end of ``oracle/stac_oracle.c`` (see ``stac_oracle.h`` for what each function
-restates and the parity status: FK and m_opt pinned, q_phase "parity unpinned").
+restates and the parity status: FK and m_opt pinned exactly, the q_phase pinned in marker space and at its
+stopping rule to the reference's stored fit demos/demo_viz.p -- tests/test_pin_demo_viz.py).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
 import this package.  Nothing under ``stac_mjx_amd/`` does.
