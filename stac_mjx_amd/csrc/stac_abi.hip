@@ -47,7 +47,7 @@ static int fail(int code, const std::string &msg) {
 // Developer switches: read from the environment ONCE, at stac_model_create, so that a variable
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
-    int flags = -1, spec = -1, specg = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
+    int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
     bool noprune = false, verbose = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
@@ -55,7 +55,7 @@ struct DebugSwitches {
     }
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
-        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG");
+        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR");
         noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
@@ -167,7 +167,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     }
     const int n_mlev = std::max((mfirst[nlev] + 1) & ~1, 2);  // even: the kernel runs two steps per loop trip
     auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
-    const int32_t ident_ql = h.c_bx + 4;  // the world entry's quaternion (1, 0, 0, 0)
+    const int32_t ident_ql = h.c_bx + kXq;  // the world entry's quaternion (1, 0, 0, 0)
     std::vector<int32_t> prog((size_t)hw + (size_t)n_mlev * W * rw, 0);
     for (int ml = 0; ml < n_mlev; ++ml)
         for (int pp = 0; pp < W; ++pp) {  // a position without work: neutral data, nothing stored
@@ -200,7 +200,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
                     const float *jp = m->h_aj_pos.data() + 3 * j;
                     for (int c = 0; c < 3; ++c) r[4 + c] = f2i(jp[c]);
                     r[7] = h.c_ja + kXf * j;
-                    ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + 4;
+                    ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + kXq;
                     prog[ml >> 1] |= FK_ML_JOINT << fsh;
                     if (jp[0] != 0.0f || jp[1] != 0.0f || jp[2] != 0.0f) prog[ml >> 1] |= FK_ML_JPOS << fsh;
                     if (ty == STAC_JNT_FREE) { r[10] = FK_KIND_FREE; r[11] = m->h_aj_qadr[j]; prog[ml >> 1] |= FK_ML_SPECIAL << fsh; }
@@ -456,7 +456,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                       // later in the trip, moves it into its own region)
     // strides of 4 x odd words: regions stay 16-byte aligned (ds_read_b128 / ds_write_b128) and the chains of one
     // wavefront start in different banks
-    auto stride_of = [](int words) { const int q = (words + 3) / 4; return 4 * (q | 1); };
+    auto stride_of = [](int words) { const int q = (words + 3) / 4; return kXf == 8 ? 4 * (q | 1) : (words | 1); };
     o = (o + 3) & ~3;
     h.stride_regs = stride_of(o);
     h.c_r2 = o; o += K > 64 ? h.kpow2 : ((K + 3) & ~3);
@@ -505,6 +505,8 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr int kCus = 256;
 // latency mode: up to this many chains a chain is spread over 8 / 4 wavefronts of a workgroup (else one per chain)
 constexpr long kSpec64MaxChains = 256, kSpec32MaxChains = 512;
+// latency mode with 4 roles per chain from this many chains on (never auto-selected below: developer switch STAC_HIP_SPECR)
+constexpr long kSpec4MinChains = 1L << 40;
 
 // Wavefronts per workgroup: the waves of a block share one copy of the plan, so more chains fit the
 // 160 KiB of a CU.  Returns the wpb (1..8) that maximises resident chains per CU for this G.
@@ -549,23 +551,25 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_need
 // G = 8: one chain per wavefront, `chains` wavefronts per workgroup; G = 32 / 64: one chain per workgroup of 4 / 8
 // wavefronts.  A chain's LDS block = 8 role regions + the exchange area (accept flags, losses, two gradients).
 static int spec_xch_words(const PlanHeader &h) { return 64 + 4 * h.nqpad + 4; }
-static size_t spec_lds_bytes(const PlanHeader &h, int G, int nkinds, int chains) {
+// nr = evaluation roles per chain: 8, or 4 (two chains per wavefront at 8 lanes per role: large batches)
+static size_t spec_lds_bytes(const PlanHeader &h, int G, int nkinds, int chains, int nr = 8) {
     const int plan_words = (h.total_words + 3) & ~3;
-    return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (8 * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float);
+    return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (nr * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float);
 }
 struct SpecShape { int G, chains_per_block, waves_per_block; long resident; };  // resident = chains the chip holds at once
-static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nchains = -1) {
+static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nchains = -1, int nr = 8) {
     constexpr size_t kGranule = 1280;
     SpecShape best{G, 0, 0, 0};
-    if (G == 8) {  // 256-VGPR kernel: two waves per SIMD, eight per CU
-        for (int c = 1; c <= 8; ++c) {
-            size_t lds = spec_lds_bytes(h, 8, nkinds, c);
+    if (G == 8) {  // 256-VGPR kernel: two waves per SIMD, eight per CU; 8 / nr chains per wavefront
+        const int cw = 8 / nr;
+        for (int w = 1; w <= 8; ++w) {
+            size_t lds = spec_lds_bytes(h, 8, nkinds, w * cw, nr);
             if (lds > kLdsPerCu) break;
             lds = (lds + kGranule - 1) / kGranule * kGranule;
-            const int blocks = std::min((int)(kLdsPerCu / lds), 8 / c);
-            const long res = (long)blocks * c * kCus;
-            if (res > best.resident) best = SpecShape{8, c, c, res};
-            if (nchains >= 0 && res >= nchains) return SpecShape{8, c, c, res};  // small workgroups spread over more CUs
+            const int blocks = std::min((int)(kLdsPerCu / lds), 8 / w);
+            const long res = (long)blocks * w * cw * kCus;
+            if (res > best.resident) best = SpecShape{8, w * cw, w, res};
+            if (nchains >= 0 && res >= nchains) return SpecShape{8, w * cw, w, res};  // small workgroups spread over more CUs
         }
         return best;
     }
@@ -742,22 +746,26 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         }
         if (dbg.specg == 8 || dbg.specg == 32 || dbg.specg == 64) sg = dbg.specg;
         if (m->h.nq > sg * (sg == 8 ? 32 : sg == 32 ? 8 : 4)) sg = 8;  // no instantiation that wide: back to one wave per chain
-        const SpecShape sh = pick_spec_shape(m->h, sg, nkinds, nchains);
+        // roles per chain: four (two candidates + their momentum points, two chains per wavefront) once the batch is so
+        // large that throughput counts, not the latency of one chain
+        int sr = (sg == 8 && (long)nchains >= kSpec4MinChains) ? 4 : 8;
+        if (sg == 8 && (dbg.specr == 4 || dbg.specr == 8)) sr = dbg.specr;
+        const SpecShape sh = pick_spec_shape(m->h, sg, nkinds, nchains, sr);
         if (sh.chains_per_block) {
-            const size_t lds = spec_lds_bytes(m->h, sg, nkinds, sh.chains_per_block);
+            const size_t lds = spec_lds_bytes(m->h, sg, nkinds, sh.chains_per_block, sr);
             if (dbg.verbose)
-                fprintf(stderr, "[stac] q_phase: chains=%d speculative, %d lanes per evaluation (%d wavefront(s) per chain), %d chain(s) per workgroup, lds=%zu B/block, resident=%ld\n",
-                        nchains, sg, std::max(sg / 8, 1), sh.chains_per_block, lds, sh.resident);
+                fprintf(stderr, "[stac] q_phase: chains=%d speculative, %d roles of %d lanes per chain (%d wavefront(s) per chain), %d chain(s) per workgroup, lds=%zu B/block, resident=%ld\n",
+                        nchains, sr, sg, std::max(sg / 8, 1), sh.chains_per_block, lds, sh.resident);
             a.mb_words = q_mb_words(nkinds, sg);
             a.h.chain_stride = q_chain_stride(m->h, sg);
             // chain queue (see below): more clips than resident chain slots -> the roles of a finished clip take the next
-            long resident = pick_spec_shape(m->h, sg, nkinds).resident / sh.chains_per_block * sh.chains_per_block;
+            long resident = pick_spec_shape(m->h, sg, nkinds, -1, sr).resident / sh.chains_per_block * sh.chains_per_block;
             if (dbg.queue > 0 && dbg.queue < nchains) resident = (long)(dbg.queue + sh.chains_per_block - 1) / sh.chains_per_block * sh.chains_per_block;
             if ((long)nchains > resident && dbg.queue != 0) {
                 HIP_TRY(launch_ctl_init(m->d_ctl, 0, 0x7fffffff, 0, 0, (int)resident, s));
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
-            e = launch_q_phase(a, sg, sh.waves_per_block, 2, 1, lds, s, &cap);
+            e = launch_q_phase(a, sg, sh.waves_per_block, 2, sr, lds, s, &cap);
             a.ctl = nullptr; a.queue_slots = 0;
         }
     }
@@ -830,7 +838,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             b.mb_words = q_mb_words(nkinds, 8);
             b.h.chain_stride = q_chain_stride(m->h, 8);
             int cap2 = 0;
-            e = launch_q_phase(b, 8, ss.waves_per_block, 2, 1, spec_lds_bytes(m->h, 8, nkinds, ss.chains_per_block), s, &cap2);
+            e = launch_q_phase(b, 8, ss.waves_per_block, 2, 8, spec_lds_bytes(m->h, 8, nkinds, ss.chains_per_block), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
             if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.waves_per_block);
         }
@@ -967,7 +975,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
     L.c_b = o; o += L.n_max;
     L.c_d = o; o += L.n_max + 2 * L.maxpd;  // step vector + two scratch rows of the L^T D L pivot loop
     L.c_fz = o; o += L.n_max;
-    L.chain_stride = 4 * (((o + 3) / 4) | 1);  // 16-byte aligned regions, chains spread over the banks
+    L.chain_stride = kXf == 8 ? 4 * (((o + 3) / 4) | 1) : (o | 1);  // 16-byte aligned regions, chains spread over the banks
     return STAC_OK;
 }
 

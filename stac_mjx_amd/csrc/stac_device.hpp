@@ -147,10 +147,25 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast<const int4 *>(p); }
 // transform entries (kXf words, 16-byte aligned: stac_plan.hpp): position in words 0-2, quaternion in words 4-7
-__device__ __forceinline__ V3 ld_tpos(const float *p) { const float4 v = lds4(p); return {v.x, v.y, v.z}; }
-__device__ __forceinline__ Q4 ld_tquat(const float *p) { const float4 v = lds4(p + 4); return {v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void st_tpos(float *p, V3 v) { *reinterpret_cast<float4 *>(p) = float4{v.x, v.y, v.z, 0.0f}; }
-__device__ __forceinline__ void st_tquat(float *p, Q4 q) { *reinterpret_cast<float4 *>(p + 4) = float4{q.w, q.x, q.y, q.z}; }
+__device__ __forceinline__ V3 ld_tpos(const float *p) {
+    if constexpr (kXf == 8) { const float4 v = lds4(p); return {v.x, v.y, v.z}; }
+    else return ld3(p);
+}
+__device__ __forceinline__ Q4 ld_tquat(const float *p) {
+    if constexpr (kXf == 8) { const float4 v = lds4(p + 4); return {v.x, v.y, v.z, v.w}; }
+    else return ld4(p + 3);
+}
+__device__ __forceinline__ void st_tpos(float *p, V3 v) {
+    if constexpr (kXf == 8) *reinterpret_cast<float4 *>(p) = float4{v.x, v.y, v.z, 0.0f};
+    else st3(p, v);
+}
+__device__ __forceinline__ void st_tquat(float *p, Q4 q) {
+    if constexpr (kXf == 8) *reinterpret_cast<float4 *>(p + 4) = float4{q.w, q.x, q.y, q.z};
+    else st4(p + 3, q);
+}
+// second vector of a wrench entry {f, t}
+__device__ __forceinline__ V3 ld_tvec2(const float *p) { return ld_tpos(p + kXq); }
+__device__ __forceinline__ void st_tvec2(float *p, V3 v) { st_tpos(p + kXq, v); }
 
 // ------------------------------------------------------------------------------------------------
 // forward kinematics of one chain out of LDS (shared by the PG and the LM kernel)
@@ -175,7 +190,7 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
             st_tquat(ja + kXf * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
         } else if (ty == JSLIDE) {
             const float4 jp4 = lds4(jr + 4);
-            ja[kXf * j + 4] = qe[ad] - jp4.w;
+            ja[kXf * j + kXq] = qe[ad] - jp4.w;
         } else {
             const int qa = ty == JFREE ? ad + 3 : ad;
             float n;
@@ -250,7 +265,7 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
                     if (!jzero) anchor = add3(rotate(jp, quat), pos);
                     const float4 ja4 = lds4(jr + 8);
                     const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
-                    const float d = ja[kXf * j + 4];
+                    const float d = ja[kXf * j + kXq];
                     pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
                 }
                 if (store_ja) {
@@ -289,7 +304,7 @@ __device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const floa
     R.r1 = lds4(rec + 4);
     R.r2 = lds4i(rec + 8);
     if constexpr (RW == 16) R.r3 = lds4(rec + 12);
-    { const float4 v = lds4(CBc + ql_off); R.ql = Q4{v.x, v.y, v.z, v.w}; }  // ql_off = words 4-7 of a transform entry: one ds_read_b128
+    R.ql = ld_tquat(CBc + ql_off - kXq);  // ql_off = the quaternion words of a transform entry
 }
 // One step: fetch the next step's record into N (its ql offset is in this record), then run this one.
 // `on`: the lane has a position in the program (the others run position 0's data, with nothing loaded or stored).

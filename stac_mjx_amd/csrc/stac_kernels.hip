@@ -52,13 +52,19 @@ namespace stac {
 // evaluations only, by all 64 lanes of the wave(s) that own them.  The solver state is replicated in every
 // role; roles exchange {accept flag, loss} and the two gradients through a small per-chain LDS area
 // (double-buffered by trip parity, so two workgroup barriers per trip suffice).
-template <int G, int NQR, int WPE, bool SPEC>
+// SPEC = number of evaluation roles per chain in latency mode (0 = throughput mode): 8 = four candidates + their four
+// momentum points; 4 = two + two (84 % of the iterations accept one of the first two candidates; the others take a
+// second trip with candidates 2 and 3): two chains per wavefront at 8 lanes per role, for large batches.
+template <int G, int NQR, int WPE, int SPEC>
 __global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
-    static_assert(!SPEC || G == 8 || G == 16 || G == 32 || G == 64, "speculative mode: 8 roles of G lanes");
+    static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 32 || G == 64)) || (SPEC == 4 && G == 8), "speculative mode: 8 (or 4) roles of G lanes");
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
-    constexpr int NW = SPEC ? (G >= 8 ? G / 8 : 1) : 1;  // SPEC: wavefronts per chain (one chain per workgroup when > 1)
+    constexpr int NR = SPEC ? SPEC : 1, NC = SPEC ? SPEC / 2 : 1;  // roles per chain, of which candidates
+    constexpr int LC = (G * NR >= 64) ? 64 : G * NR;                // lanes of one wavefront that work on one chain
+    constexpr int NW = SPEC ? (G * NR >= 64 ? G * NR / 64 : 1) : 1; // SPEC: wavefronts per chain (one chain per workgroup when > 1)
+    constexpr int CW = SPEC ? 64 / LC : 1;                          // SPEC, NW == 1: chains per wavefront
     const PlanHeader &H = a.h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int grp = lane / G, lg = lane % G;
@@ -89,11 +95,12 @@ void q_phase_kernel(const QArgs a) {
     }
     // SPEC: a chain's block = 8 role regions + the exchange area; the block's waves share it (NW > 1) or own one each
     const int xch_words = 64 + 4 * nqpad + 4;
-    const int cblock_words = 8 * H.chain_stride + xch_words;
-    float *CBw = lds + plan_words + a.mb_words + (SPEC ? (NW > 1 ? 0 : wave) * cblock_words : wave * CPW * H.chain_stride);
-    const int role = SPEC ? (NW > 1 ? wave * CPW + grp : grp) : grp;
+    const int cblock_words = NR * H.chain_stride + xch_words;
+    const int cidx = SPEC ? (NW > 1 ? 0 : grp / NR) : 0;  // SPEC, NW == 1: this lane's chain among the wavefront's
+    float *CBw = lds + plan_words + a.mb_words + (SPEC ? (NW > 1 ? 0 : wave * CW + cidx) * cblock_words : wave * CPW * H.chain_stride);
+    const int role = SPEC ? (NW > 1 ? wave * CPW + grp : grp % NR) : grp;
     float *CB = CBw + (SPEC ? role : grp) * H.chain_stride;  // this evaluation's (chain's) region
-    float *XB = CBw + 8 * H.chain_stride;  // SPEC: [2][8][4] {accept, loss}, [2][2][nqpad] gradients, [4] queue word
+    float *XB = CBw + NR * H.chain_stride;  // SPEC: [2][8][4] {accept, loss}, [2][2][nqpad] gradients, [4] queue word
     int trip_parity = 0;
     auto chain_sync = [&]() {  // all lanes that work on this chain
         if constexpr (NW > 1) __syncthreads();
@@ -117,7 +124,7 @@ void q_phase_kernel(const QArgs a) {
     const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
     // ---- per-chain solver state (uniform inside a group) ------------------------------------------
-    const int slot_id = SPEC ? (NW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * wpb + wave)) : (int)(blockIdx.x * wpb + wave) * CPW + grp;
+    const int slot_id = SPEC ? (NW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * wpb + wave) * CW + cidx) : (int)(blockIdx.x * wpb + wave) * CPW + grp;
     const int hstride = 3 * nqpad + 12;
     // resume = 1: this launch continues the chains that the throughput kernel handed off (QArgs::ctl / hand)
     const bool resuming = a.resume != 0 && slot_id < a.ctl[2] && slot_id < a.ctl[3];
@@ -259,7 +266,7 @@ void q_phase_kernel(const QArgs a) {
         const bool ls_with_grad = (st_in == ST_LS) && !(a.flags & 1) && (nls >= 1 || any_grad);
         // t_next and the momentum coefficient of the running iteration (functions of t only; recomputed every
         // trip instead of being carried); SPEC: this group's candidate scale 2^-c
-        const float spec_pow = SPEC ? ((role & 3) == 0 ? 1.0f : (role & 3) == 1 ? 0.5f : (role & 3) == 2 ? 0.25f : 0.125f) : 1.0f;
+        const float spec_pow = SPEC ? ((role % NC) == 0 ? 1.0f : (role % NC) == 1 ? 0.5f : (role % NC) == 2 ? 0.25f : 0.125f) : 1.0f;
         const float spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
         const float spec_beta = (t - 1.0f) / spec_tn;
 
@@ -274,7 +281,7 @@ void q_phase_kernel(const QArgs a) {
                 if (SPEC && st_in == ST_SPEC) {
                     const float ec = eta * spec_pow;  // eta / 2^c (exact)
                     const float cr = clipf(FMA(-ec, g[r], y[r]), lbv[e], ubv[e]);
-                    pt = role < 4 ? cr : FMA(spec_beta, cr - x[r], cr);
+                    pt = role < NC ? cr : FMA(spec_beta, cr - x[r], cr);
                 } else {
                     pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? CAND(r, e) : x[r]);
                 }
@@ -324,7 +331,7 @@ void q_phase_kernel(const QArgs a) {
                 if (wz) tq = V3{0.0f, 0.0f, 0.0f};
                 const int sp = ss >> 16;
                 st_tpos(sw + kXf * sp, f);
-                st_tpos(sw + kXf * sp + 4, tq);
+                st_tvec2(sw + kXf * sp, tq);
             }
             return FMA(rz, rz, FMA(ry, ry, rx * rx));
         };
@@ -400,16 +407,16 @@ void q_phase_kernel(const QArgs a) {
             for (; i + 4 <= rr.hi; i += 4) {  // same left-to-right order; four wrenches in flight per LDS round trip
                 V3 f4[4], t4[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { f4[u] = ld_tpos(swx + kXf * (i + u)); t4[u] = ld_tpos(swx + kXf * (i + u) + 4); }
+                for (int u = 0; u < 4; ++u) { f4[u] = ld_tpos(swx + kXf * (i + u)); t4[u] = ld_tvec2(swx + kXf * (i + u)); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { Fs = add3(Fs, f4[u]); T0 = add3(T0, t4[u]); }
             }
             for (; i < rr.hi; ++i) {
                 Fs = add3(Fs, ld_tpos(swx + kXf * i));
-                T0 = add3(T0, ld_tpos(swx + kXf * i + 4));
+                T0 = add3(T0, ld_tvec2(swx + kXf * i));
             }
             st_tpos(CBx + H.c_rw + kXf * r, Fs);
-            st_tpos(CBx + H.c_rw + kXf * r + 4, T0);
+            st_tvec2(CBx + H.c_rw + kXf * r, T0);
         };
         // (B) one joint: its range's wrench, then the joint formulas; crefx = the root position the moments refer to
         auto joint_gradient = [&](const int j, float *CBx, const V3 crefx, float *ggx) {
@@ -419,7 +426,7 @@ void q_phase_kernel(const QArgs a) {
             const int ty = ji.x, ad = ji.y;
             const float4 ja4 = lds4(jr + 8);  // axis, range id
             const float *rw = CBx + H.c_rw + kXf * __builtin_bit_cast(int, ja4.w);
-            const V3 Fs = ld_tpos(rw), T0 = ld_tpos(rw + 4);
+            const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
                 const V3 anchor = ld_tpos(jax_ + kXf * j);
                 const Q4 prequat = ld_tquat(jax_ + kXf * j);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
@@ -569,12 +576,12 @@ void q_phase_kernel(const QArgs a) {
         }
 
 
-        if (SPEC && __any(st_in == ST_SPEC)) {  // the whole chain is in this state: the solver state is replicated
+        if (SPEC && st_in == ST_SPEC) {  // every lane of the chain is in this state: the solver state is replicated
             // (1) which candidate would the sequential line search take?  Candidate n = nls + c is evaluated
             //     only while n < maxls; candidate n == maxls is taken without evaluation (jaxopt's loop bound).
             const float ec = eta * spec_pow;
             const bool ok = !(ec * (loss - fy) > ec * sum1 + 0.5f * sum0 + eps);  // sufficient decrease (own candidate)
-            const bool take = role < 4 && (ok || nls + role >= a.maxls);
+            const bool take = role < NC && (ok || nls + role >= a.maxls);
             float *xc = XB + trip_parity * 32;
             if (lg == 0) { xc[4 * role] = take ? 1.0f : 0.0f; xc[4 * role + 1] = loss; }
             PROF_TICK(8);
@@ -582,12 +589,12 @@ void q_phase_kernel(const QArgs a) {
             PROF_TICK(4);  // latency mode: wait for the other roles' losses
             int cs = -1;  // first accepting role = c*
 #pragma unroll
-            for (int c = 3; c >= 0; --c)
+            for (int c = NC - 1; c >= 0; --c)
                 if (xc[4 * c] != 0.0f) cs = c;
-            if (cs < 0) {  // none of the four: halve four more times
-                eta = eta * 0.0625f;
-                nls += 4;
-                c_ls += 4;
+            if (cs < 0) {  // none of the NC candidates: halve NC more times
+                eta = eta * (NC == 4 ? 0.0625f : 0.25f);
+                nls += NC;
+                c_ls += NC;
             } else {
                 const int evaluated = (nls + cs >= a.maxls) ? cs : cs + 1;
                 const float pw = cs == 0 ? 1.0f : cs == 1 ? 0.5f : cs == 2 ? 0.25f : 0.125f;
@@ -596,21 +603,22 @@ void q_phase_kernel(const QArgs a) {
                 //     stopping residual) and the momentum point it leads to (role 4 + c*, the next iteration's grad f).
                 //     The wave(s) owning them run the joint pass with all 64 lanes; every role then reads both vectors.
                 float *gxa = XB + 64 + trip_parity * 2 * nqpad, *gxn = gxa + nqpad;
-                float *CBa = CBw + cs * H.chain_stride, *CBn = CBw + (4 + cs) * H.chain_stride;
-                if constexpr (NW == 1) {
+                float *CBa = CBw + cs * H.chain_stride, *CBn = CBw + (NC + cs) * H.chain_stride;
+                if constexpr (NW == 1) {  // the LC lanes of this wavefront that work on the chain share both gradient passes
+                    const int ll = lane % LC;
                     const V3 crefa = ld_tpos(CBa + H.c_bx + kXf), crefn = ld_tpos(CBn + H.c_bx + kXf);
-                    for (int e = lane; e < nqpad; e += 64) { gxa[e] = 0.0f; gxn[e] = 0.0f; }
-                    for (int i = lane; i < 2 * H.nrange; i += 64) {
+                    for (int e = ll; e < nqpad; e += LC) { gxa[e] = 0.0f; gxn[e] = 0.0f; }
+                    for (int i = ll; i < 2 * H.nrange; i += LC) {
                         const bool nx = i >= H.nrange;
                         range_sum(nx ? i - H.nrange : i, nx ? CBn : CBa);
                     }
                     wave_sync();
-                    for (int i = lane; i < 2 * H.naj; i += 64) {
+                    for (int i = ll; i < 2 * H.naj; i += LC) {
                         const bool nx = i >= H.naj;
                         joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa, nx ? crefn : crefa, nx ? gxn : gxa);
                     }
                 } else {
-                    const bool mine_a = cs / CPW == wave, mine_n = (4 + cs) / CPW == wave;  // wave-uniform
+                    const bool mine_a = cs / CPW == wave, mine_n = (NC + cs) / CPW == wave;  // wave-uniform
                     if (mine_a || mine_n) {
                         float *gx = mine_a ? gxa : gxn, *CBx = mine_a ? CBa : CBn;
                         const V3 crefx = ld_tpos(CBx + H.c_bx + kXf);
@@ -646,7 +654,7 @@ void q_phase_kernel(const QArgs a) {
                 const float e2 = group_tree_sum<G, NQR>(t0);  // the same value in every role
                 const float fx_c = xc[4 * cs + 1];
                 // (3) f at the next momentum point comes from role 4 + c*
-                const float fy_next = xc[4 * (4 + cs) + 1];
+                const float fy_next = xc[4 * (NC + cs) + 1];
                 c_ls += evaluated;
                 c_grad += 1;  // the gradient at x_next (the oracle's VG_X evaluation)
                 const float next_step = (eacc <= 1e-6f) ? 1.0f : eacc / 0.5f;
@@ -751,8 +759,8 @@ void q_phase_kernel(const QArgs a) {
                                         nxt = xq[0];
                                         __syncthreads();
                                     } else {
-                                        if (SPEC ? lane == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
-                                        nxt = __shfl(nxt, SPEC ? 0 : grp * G, 64);
+                                        if (SPEC ? (lane % LC) == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
+                                        nxt = __shfl(nxt, SPEC ? (lane / LC) * LC : grp * G, 64);
                                     }
                                     if (nxt < a.C) begin_chain(nxt);
                                 }
@@ -922,10 +930,11 @@ hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4,
     return hipGetLastError();
 }
 
-template <int G, int NQR, int WPE, bool SPEC>
+template <int G, int NQR, int WPE, int SPEC>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
-    constexpr int CPW = SPEC ? 1 : 64 / G;
-    constexpr int NW = SPEC ? G / 8 : 1;  // SPEC: wavefronts per chain; more than one -> one chain per workgroup
+    constexpr int NR = SPEC ? SPEC : 1;
+    constexpr int NW = SPEC ? (G * NR >= 64 ? G * NR / 64 : 1) : 1;  // SPEC: wavefronts per chain; more than one -> one chain per workgroup
+    constexpr int CPW = SPEC ? (G * NR >= 64 ? 1 : 64 / (G * NR)) : 64 / G;  // chains per wavefront
     if (NW > 1) wpb = NW;
     const int per_block = NW > 1 ? 1 : CPW * wpb;
     // a resume launch has one slot per hand-off entry; with a chain queue the grid covers the resident slots only
@@ -945,14 +954,15 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     const int nq = a.h.nq;
     *capacity_out = 0;
     if (spec) {
-#define STAC_TRY_SPEC(GG, RR, WW)                                    \
-    if (G == GG && nq <= GG * RR) {                                  \
+#define STAC_TRY_SPEC(GG, RR, WW, NRR)                               \
+    if (G == GG && spec == NRR && nq <= GG * RR) {                   \
         *capacity_out = GG * RR;                                     \
-        return launch_q<GG, RR, WW, true>(a, wpb, lds_bytes, s);     \
+        return launch_q<GG, RR, WW, NRR>(a, wpb, lds_bytes, s);      \
     }
-        STAC_TRY_SPEC(8, 10, 2) STAC_TRY_SPEC(8, 16, 2) STAC_TRY_SPEC(8, 32, 2)
-        STAC_TRY_SPEC(32, 3, 2) STAC_TRY_SPEC(32, 8, 2)
-        STAC_TRY_SPEC(64, 2, 2) STAC_TRY_SPEC(64, 4, 2)
+        STAC_TRY_SPEC(8, 10, 2, 4) STAC_TRY_SPEC(8, 16, 2, 4) STAC_TRY_SPEC(8, 32, 2, 4)
+        STAC_TRY_SPEC(8, 10, 2, 8) STAC_TRY_SPEC(8, 16, 2, 8) STAC_TRY_SPEC(8, 32, 2, 8)
+        STAC_TRY_SPEC(32, 3, 2, 8) STAC_TRY_SPEC(32, 8, 2, 8)
+        STAC_TRY_SPEC(64, 2, 2, 8) STAC_TRY_SPEC(64, 4, 2, 8)
 #undef STAC_TRY_SPEC
         return hipErrorInvalidValue;
     }
@@ -960,10 +970,10 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     if (G == GG && nq <= GG * RR) {                                               \
         *capacity_out = GG * RR;                                                  \
         if constexpr (GG == 16) {                                                 \
-            if (wpe == 3) return launch_q<GG, RR, 3, false>(a, wpb, lds_bytes, s); \
+            if (wpe == 3) return launch_q<GG, RR, 3, 0>(a, wpb, lds_bytes, s);     \
         }                                                                         \
-        return wpe >= 4 ? launch_q<GG, RR, 4, false>(a, wpb, lds_bytes, s)        \
-                        : launch_q<GG, RR, 2, false>(a, wpb, lds_bytes, s);       \
+        return wpe >= 4 ? launch_q<GG, RR, 4, 0>(a, wpb, lds_bytes, s)            \
+                        : launch_q<GG, RR, 2, 0>(a, wpb, lds_bytes, s);           \
     }
     STAC_TRY(4, 20) STAC_TRY(4, 32)
     STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)

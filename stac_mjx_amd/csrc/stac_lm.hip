@@ -172,7 +172,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             const V3 fv = {-2.0f * rx, -2.0f * ry, -2.0f * rz};
             const int sp = ss >> 16;
             st_tpos(sw + kXf * sp, fv);
-            st3(sw + kXf * sp + 4, cross3(sub3(sx, cref), fv));
+            st_tvec2(sw + kXf * sp, cross3(sub3(sx, cref), fv));
             st3(sxs + 3 * sp, sx);
             r2[k] = FMA(rz, rz, FMA(ry, ry, rx * rx));
         }
@@ -195,7 +195,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             V3 Fs = {0.f, 0.f, 0.f}, T0 = {0.f, 0.f, 0.f};
             for (int i = ji.z; i < ji.w; ++i) {
                 Fs = add3(Fs, ld_tpos(sw + kXf * i));
-                T0 = add3(T0, ld3(sw + kXf * i + 4));
+                T0 = add3(T0, ld_tvec2(sw + kXf * i));
             }
             const V3 anchor = ld_tpos(ja + kXf * j);
             const Q4 prequat = ld_tquat(ja + kXf * j);
@@ -203,7 +203,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             if (ty == JHINGE || ty == JSLIDE) {
                 const float4 ja4 = lds4(jr + 8);
                 const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, prequat);
-                st3(ja + kXf * j + 4, axis);
+                st3(ja + kXf * j + kXq, axis);
                 gg[ad] = ty == JHINGE ? dot3(axis, tau) : dot3(axis, Fs);
             } else if (ty == JFREE) {
                 st3(gg + ad, Fs);
@@ -281,7 +281,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                     g2.ty = reinterpret_cast<const int *>(jr)[0];
                     g2.comp = dr.z;
                     g2.anchor = ld_tpos(ja + kXf * dr.y);
-                    g2.axis = ld3(ja + kXf * dr.y + 4);
+                    g2.axis = ld3(ja + kXf * dr.y + kXq);
                     g2.qh = Q4{1.f, 0.f, 0.f, 0.f};
                     g2.dn = 1.0f;
                     if (g2.ty == JFREE) {

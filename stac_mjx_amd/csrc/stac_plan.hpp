@@ -13,11 +13,17 @@ constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 // A lane of a G-lane group takes the sites k = r * G + lane, r < kSiteRounds: their keypoints and loss terms stay in
 // registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
 constexpr int kSiteRounds = 3;
-// A transform entry in a chain's LDS region: position in words 0-2 (word 3 unused), quaternion in words 4-7, 16-byte
-// aligned so that it moves with two ds_read_b128 / ds_write_b128 (seven scalar words took four store instructions, and
-// LDS instruction issue, not bandwidth, is what a lone wavefront pays for).  Used for the body transforms (c_bx) and
-// the per-joint {anchor, pre-joint quaternion} entries (c_ja; the pre-pass parks the joint-local quaternion in 4-7).
-constexpr int kXf = 8;
+// A transform entry in a chain's LDS region: position (3 words) then quaternion (4 words).  Used for the body
+// transforms (c_bx), the per-joint {anchor, pre-joint quaternion} entries (c_ja; the pre-pass parks the joint-local
+// quaternion in the quaternion words) and, as {f, t}, for the site wrenches and range sums.  Packed (7 words) by
+// default; -DSTAC_XF_WORDS=8 pads the entries to 16 bytes so that they move with two ds_read_b128 / ds_write_b128
+// instead of four scalar-pair instructions.  Measured: the aligned form is neutral in the latency modes and costs the
+// throughput modes 3-15 % (12 % more LDS per chain = fewer resident chains), so packed it is.
+#ifndef STAC_XF_WORDS
+#define STAC_XF_WORDS 7
+#endif
+constexpr int kXf = STAC_XF_WORDS;     // 8 (aligned, ds_*_b128) or 7 (packed: 12 % less LDS per chain, scalar LDS accesses)
+constexpr int kXq = kXf == 8 ? 4 : 3;  // word of the quaternion (second vector) inside an entry
 
 // Records are 16-byte aligned so the kernel fetches them with ds_read_b128.
 struct BodyRec {      // 12 words
@@ -69,7 +75,7 @@ struct FkStep {       // 12 words (+4 when some active body has a non-identity b
     int32_t ja_off;   // this joint's anchor / pre-joint quaternion entry (c_ja + kXf * j), -1 = no joint in this step
     int32_t xf_off;   // where the body's transform goes after this step (c_bx + kXf * index), -1 = not stored
     int32_t ql_next;  // joint-local quaternion of this position's NEXT step (fetched one step ahead), or the
-                      // identity quaternion of the world entry (c_bx + 4)
+                      // identity quaternion of the world entry (c_bx + kXq)
     int32_t kind;     // FK_KIND_*
     int32_t aux;      // free: qpos address; slide: active joint index
     // float bquat[4] follows when PlanHeader::fk_rec_words == 16

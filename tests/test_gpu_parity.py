@@ -760,3 +760,20 @@ def test_latency_mode_chain_queue(rodent_setup, rodent_mocap, monkeypatch, specg
     ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
     _compare_phase(res, ref)
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
+
+
+def test_latency_mode_four_roles_per_chain(rodent_setup, rodent_mocap, monkeypatch):
+    """STAC_HIP_SPECR=4 (developer switch; never auto-selected): two candidates + their momentum points per trip, two
+    chains per wavefront; iterations that accept neither of the first two candidates take a second trip with candidates
+    2 and 3.  Same answers as the oracle, with the chain queue on top."""
+    monkeypatch.setenv("STAC_HIP_SPEC", "1")
+    monkeypatch.setenv("STAC_HIP_SPECG", "8")
+    monkeypatch.setenv("STAC_HIP_SPECR", "4")
+    monkeypatch.setenv("STAC_HIP_QUEUE", "4")
+    fs = rodent_setup
+    kp = rodent_mocap[700:733].reshape(11, 3, 69)
+    for maxls in (15, 3):
+        eng, orc = _engine(fs, maxiter=40, maxls=maxls), _oracle(fs, maxiter=40, maxls=maxls)
+        res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                          root_dims=fs.root_dims, do_root_opt=True)
+        _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims))
