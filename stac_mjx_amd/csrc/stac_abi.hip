@@ -172,7 +172,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     for (int ml = 0; ml < n_mlev; ++ml)
         for (int pp = 0; pp < W; ++pp) {  // a position without work: neutral data, nothing stored
             int32_t *r = prog.data() + hw + ((size_t)ml * W + pp) * rw;
-            r[3] = -1; r[7] = -1; r[8] = -1; r[9] = ident_ql; r[10] = FK_KIND_PLAIN;
+            r[6] = -1; r[7] = h.c_sink; r[8] = h.c_sink; r[9] = ident_ql; r[10] = FK_KIND_PLAIN;
             if (rw == 16) r[12] = f2i(1.0f);
         }
     std::vector<int32_t> ql_of((size_t)n_mlev * W, ident_ql);  // ql offset of every (micro-level, position)
@@ -184,12 +184,12 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
             for (int i = 0; i < nsteps; ++i) {
                 const int ml = mfirst[l] + i;
                 int32_t *r = prog.data() + hw + ((size_t)ml * W + pp) * rw;
-                const int fsh = 8 * (ml & 1);
+                const int fsh = 16 * (ml & 1);
                 if (i == 0) {
                     prog[ml >> 1] |= FK_ML_BODY << fsh;
                     if (!(br.flags & 1)) prog[ml >> 1] |= FK_ML_BQUAT << fsh;
                     if (!(br.flags & 2)) {  // the parent's transform comes from LDS (another lane produced it, or the world)
-                        r[3] = h.c_bx + kXf * br.parent;
+                        r[6] = h.c_bx + kXf * br.parent;
                         prog[ml >> 1] |= FK_ML_PARENT_LDS << fsh;
                     }
                     for (int c = 0; c < 3; ++c) r[c] = f2i(br.pos[c]);
@@ -198,7 +198,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
                 if (i < njs) {
                     const int j = m->h_ab_jadr[s] + i, ty = m->h_aj_type[j];
                     const float *jp = m->h_aj_pos.data() + 3 * j;
-                    for (int c = 0; c < 3; ++c) r[4 + c] = f2i(jp[c]);
+                    for (int c = 0; c < 3; ++c) r[3 + c] = f2i(jp[c]);
                     r[7] = h.c_ja + kXf * j;
                     ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + kXq;
                     prog[ml >> 1] |= FK_ML_JOINT << fsh;
@@ -212,6 +212,15 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     for (int ml = 0; ml + 1 < n_mlev; ++ml)
         for (int pp = 0; pp < W; ++pp) prog[hw + ((size_t)ml * W + pp) * rw + 9] = ql_of[(size_t)(ml + 1) * W + pp];
     for (int pp = 0; pp < W; ++pp) prog[(h.n_mlev_hdr >> 1) + pp] = ql_of[pp];  // first steps: fetched by the prologue
+    for (int ml = 0; ml < n_mlev; ++ml) {  // step form (FK_FORM_*) next to the flags
+        const int fsh = 16 * (ml & 1), fl = (prog[ml >> 1] >> fsh) & 255;
+        int form = FK_FORM_GENERAL;
+        if ((fl & (FK_ML_JOINT | FK_ML_JPOS | FK_ML_SPECIAL | FK_ML_BQUAT)) == (FK_ML_JOINT | FK_ML_JPOS)) {
+            if (!(fl & FK_ML_PARENT_LDS)) form = (fl & FK_ML_BODY) ? FK_FORM_BODY_JOINT : FK_FORM_JOINT;
+            else if (fl & FK_ML_BODY) form = FK_FORM_PARENT_BODY_JOINT;
+        }
+        prog[ml >> 1] |= form << (fsh + 8);
+    }
     *n_mlev_out = n_mlev;
     return prog;
 }
@@ -439,7 +448,8 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.c_jn = o; o += std::max(nqj, 1);
     h.c_qsv = o; o += 4 * nqj;
     o = (o + 3) & ~3;
-    h.c_sw = o; o += std::max(K * kXf, h.nqpad);
+    h.c_sw = o; o += std::max(K * kXf, h.nqpad + kXf);  // (+ kXf: the tail entry is the FK program's store sink, c_sink)
+    h.c_sink = o - kXf;
     o = (o + 3) & ~3;
     h.kpow2 = 1;
     while (h.kpow2 < K) h.kpow2 <<= 1;

@@ -292,8 +292,8 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
 // per-micro-level flag word (wave-uniform) says when some position needs a parent that another lane produced or has
 // a free / slide joint.  Requires max_width <= gf.  Bit-identical to fk_levels.
 struct FkRegs {
-    float4 r0;  // bpos | par_off
-    float4 r1;  // jpos | ja_off
+    float4 r0;  // bpos | jpos.x
+    float4 r1;  // jpos.yz | par_off, ja_off
     int4 r2;    // xf_off, ql_next, kind, aux
     float4 r3;  // body_quat (records of 16 words)
     Q4 ql;      // joint-local quaternion of the step's joint (identity: none)
@@ -313,7 +313,7 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
                                         V3 &pos, Q4 &quat, float *CBc, const float *qe, const float *jrec, const bool store_ja) {
     fk_fetch<RW>(N, next_rec, CBc, R.r2.y);
     if (mlf & FK_ML_PARENT_LDS) {  // wave-uniform: some position starts a body whose parent another lane (or nobody) produced
-        const int po = __builtin_bit_cast(int, R.r0.w);
+        const int po = __builtin_bit_cast(int, R.r1.z);
         if (on && po >= 0) {
             pos = ld_tpos(CBc + po);
             quat = ld_tquat(CBc + po);
@@ -325,7 +325,7 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
     if constexpr (RW == 16) {
         if (mlf & FK_ML_BQUAT) quat = qmul(quat, Q4{R.r3.x, R.r3.y, R.r3.z, R.r3.w});
     }
-    const V3 jp = {R.r1.x, R.r1.y, R.r1.z};
+    const V3 jp = {R.r0.w, R.r1.x, R.r1.y};
     const V3 pos0 = pos;
     const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
     V3 anchor = pos;
@@ -348,11 +348,11 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
         }
     }
     const int jo = __builtin_bit_cast(int, R.r1.w);
-    if (store_ja && on && jo >= 0) {
+    if (store_ja && on) {  // (a step without a joint aims at the sink entry)
         st_tpos(CBc + jo, anchor);
         st_tquat(CBc + jo, prequat);
     }
-    if (on && R.r2.x >= 0) {
+    if (on) {
         st_tpos(CBc + R.r2.x, pos);
         st_tquat(CBc + R.r2.x, quat);
     }
@@ -363,8 +363,8 @@ __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, 
                                            const bool active, const bool store_ja, const int prog_off, const int n_ml) {
     const int W = H.max_width;
     const bool on = active && lf < W;
-    // header: one word per PAIR of micro-levels (flags of step ml | flags of step ml + 1 << 8), then the ql offset of
-    // every position's first step
+    // header: one word per PAIR of micro-levels (16 bits each: flags | form << 8), then the ql offset of every
+    // position's first step
     const int *hdr = reinterpret_cast<const int *>(P + prog_off);
     const float *sp = P + prog_off + H.fk_hdr_words + RW * (on ? lf : 0);
     const float *jrec = P + H.off_joint;
@@ -383,18 +383,331 @@ __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, 
         sp += stride;
         fk_step<RW>(A, B, sp, fl & 255, on, pos, quat, CBc, qe, jrec, store_ja);
         if (ml + 2 < n_ml) sp += stride;
-        fk_step<RW>(B, A, sp, (fl >> 8) & 255, on, pos, quat, CBc, qe, jrec, store_ja);
+        fk_step<RW>(B, A, sp, (fl >> 16) & 255, on, pos, quat, CBc, qe, jrec, store_ja);
     }
 }
 
-// FK of one chain by gf lanes: the program when every level fits the lanes, else the level loop.
+// ---- the same program, FOUR lanes per position ------------------------------------------------------------------
+// Lane c = 0..3 of a quad owns component c of the running quaternion (w, x, y, z) and, for c >= 1, component c - 1
+// of the running position.  Every result component is the scalar code's own mul / fma sequence (same operands,
+// same order: bit-identical), with the other components fetched through quad_perm DPP operands:
+//   qmul   r_c = u.w v_c +- u.x v_p1(c) +- u.y v_p2(c) +- u.z v_p3(c)           4 instructions instead of 16
+//   rotate r_c = s2 (u x v)_c + (k v_c + t u_c)                                 9 instead of 24
+// plus, once per new quaternion, its broadcasts and the v-independent terms (u.u, k, s2).  A step costs about half
+// the instructions of the one-lane-per-position form, and in the trees at hand (at most four bodies side by side)
+// the lanes were idle anyway.  Needs 4 * max_width <= lanes of the group.
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, true));
+}
+struct QuadQuat {
+    float qc;              // own component
+    float S, UX, UY, UZ;   // broadcasts of w, x, y, z
+    float U1, U2;          // u_(c+1), u_(c+2) in the cyclic order x -> y -> z -> x (lanes 1-3)
+    float K, S2;           // s^2 - u.u, 2 s
+    float SX, SY, SZ;      // +-u.x, +-u.y, +-u.z with the signs of this lane's row of the quaternion product
+};
+__device__ __forceinline__ void quad_derive(QuadQuat &Q, const float qc, const int m1, const int m2, const int m3) {
+    Q.qc = qc;
+    Q.S = quad_dpp<0x00>(qc);
+    Q.UX = quad_dpp<0x55>(qc);
+    Q.UY = quad_dpp<0xAA>(qc);
+    Q.UZ = quad_dpp<0xFF>(qc);
+    Q.U1 = quad_dpp<0x78>(qc);  // [0,2,3,1]
+    Q.U2 = quad_dpp<0x9C>(qc);  // [0,3,1,2]
+    const float uu = FMA(Q.UZ, Q.UZ, FMA(Q.UY, Q.UY, Q.UX * Q.UX));
+    Q.K = FMA(Q.S, Q.S, -uu);
+    Q.S2 = Q.S + Q.S;
+    Q.SX = __builtin_bit_cast(float, __builtin_bit_cast(int, Q.UX) ^ m1);
+    Q.SY = __builtin_bit_cast(float, __builtin_bit_cast(int, Q.UY) ^ m2);
+    Q.SZ = __builtin_bit_cast(float, __builtin_bit_cast(int, Q.UZ) ^ m3);
+}
+// The compiler folds a quad_perm operand into v_mul_f32 but not into v_fmac_f32 (it leaves a v_mov_b32_dpp in front of
+// every fma), so the two kernels of the step are written out.  Hazards the assembler does not see inside a block: a DPP
+// operand needs two wait states after a VALU write of its register (the leading s_nop: the operand may have just been
+// copied), and so do the compiler's DPP moves that consume a block's result (trailing s_nop of quad_qmul, whose
+// result feeds quad_derive).
+#define STAC_DPP(p) " quad_perm:[" p "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// component c - 1 of rotate(v, q) in lane c >= 1 (vd = the lane's component of v); lane 0 holds no meaning
+__device__ __forceinline__ float quad_rotate(const float vd, const QuadQuat &Q) {
+    float uv, m, r;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %3, %4" STAC_DPP("1,1,1,1")    // uv = v.x u.x
+        "v_mul_f32_dpp %1, %3, -%8" STAC_DPP("0,2,3,1")   // m = -(u_(c+2) v_(c+1))
+        "v_fmac_f32_dpp %0, %3, %5" STAC_DPP("2,2,2,2")   //    + v.y u.y
+        "v_fmac_f32_dpp %1, %3, %7" STAC_DPP("0,3,1,2")   // m = u_(c+1) v_(c+2) - u_(c+2) v_(c+1)
+        "v_fmac_f32_dpp %0, %3, %6" STAC_DPP("3,3,3,3")   //    + v.z u.z
+        "v_add_f32 %0, %0, %0\n\t"                        // t = 2 u.v
+        "v_mul_f32 %2, %0, %9\n\t"                        // t u_c
+        "v_fmac_f32 %2, %10, %3\n\t"                      // + k v_c
+        "v_fmac_f32 %2, %11, %1"                          // + s2 (u x v)_c
+        : "=&v"(uv), "=&v"(m), "=&v"(r)
+        : "v"(vd), "v"(Q.UX), "v"(Q.UY), "v"(Q.UZ), "v"(Q.U1), "v"(Q.U2), "v"(Q.qc), "v"(Q.K), "v"(Q.S2));
+    return r;
+}
+// component c of qmul(q, v) (vq = the lane's component of v)
+__device__ __forceinline__ float quad_qmul(const QuadQuat &Q, const float vq) {
+    float r;
+    asm("s_nop 0\n\t"
+        "v_mul_f32 %0, %1, %2\n\t"
+        "v_fmac_f32_dpp %0, %2, %3" STAC_DPP("1,0,3,2")
+        "v_fmac_f32_dpp %0, %2, %4" STAC_DPP("2,3,0,1")
+        "v_fmac_f32_dpp %0, %2, %5" STAC_DPP("3,2,1,0")
+        "s_nop 1"
+        : "=&v"(r)
+        : "v"(Q.S), "v"(vq), "v"(Q.SX), "v"(Q.SY), "v"(Q.SZ));
+    return r;
+}
+// The common step in one block: the three chains that depend on the incoming quaternion only -- body offset
+// rotate(bpos, q), anchor offset rotate(jpos, q), and q * ql with the broadcasts / u.u / k of the product -- are
+// interleaved by hand (a lone wavefront issues a DEPENDENT VALU instruction only every ~8 cycles, an independent
+// one every 4; the compiler schedules an asm block as a unit).  Same operations, same operands, same order per
+// result as quad_rotate / quad_qmul / quad_derive.  On return: pcb = pc + rotate(bpos, q) (BODY) or pc;
+// ra = rotate(jpos, q); Qn = everything of the new quaternion except S2 and the signed copies.
+template <bool BODY>
+__device__ __forceinline__ void quad_joint_fused(const float pc, const QuadQuat &Q, const float vb, const float vj, const float ql,
+                                                 float &pcb, float &ra, QuadQuat &Qn) {
+    float r, nS, nUX, nUY, nUZ, nU1, nU2, nK, tB, tA, mB;
+    if constexpr (BODY) {
+        asm("s_nop 0\n\t"
+            "v_mul_f32 %0, %13, %27\n\t"                          // M  r = s ql_c
+            "v_mul_f32_dpp %8, %25, %14" STAC_DPP("1,1,1,1")      // B  uv = bpos.x u.x
+            "v_mul_f32_dpp %9, %26, %14" STAC_DPP("1,1,1,1")      // A  uv = jpos.x u.x
+            "v_fmac_f32_dpp %0, %27, %22" STAC_DPP("1,0,3,2")     // M
+            "v_mul_f32_dpp %10, %25, -%18" STAC_DPP("0,2,3,1")    // B  m = -(u_(c+2) bpos_(c+1))
+            "v_mul_f32_dpp %11, %26, -%18" STAC_DPP("0,2,3,1")    // A
+            "v_fmac_f32_dpp %0, %27, %23" STAC_DPP("2,3,0,1")     // M
+            "v_fmac_f32_dpp %8, %25, %15" STAC_DPP("2,2,2,2")     // B
+            "v_fmac_f32_dpp %9, %26, %15" STAC_DPP("2,2,2,2")     // A
+            "v_fmac_f32_dpp %0, %27, %24" STAC_DPP("3,2,1,0")     // M  r = component c of q * ql
+            "v_fmac_f32_dpp %10, %25, %17" STAC_DPP("0,3,1,2")    // B
+            "v_fmac_f32_dpp %11, %26, %17" STAC_DPP("0,3,1,2")    // A
+            "v_fmac_f32_dpp %8, %25, %16" STAC_DPP("3,3,3,3")     // B
+            "v_fmac_f32_dpp %9, %26, %16" STAC_DPP("3,3,3,3")     // A
+            "v_mov_b32_dpp %1, %0" STAC_DPP("0,0,0,0")            // M  broadcasts of the product
+            "v_mov_b32_dpp %2, %0" STAC_DPP("1,1,1,1")
+            "v_mov_b32_dpp %3, %0" STAC_DPP("2,2,2,2")
+            "v_mov_b32_dpp %4, %0" STAC_DPP("3,3,3,3")
+            "v_add_f32 %8, %8, %8\n\t"                            // B  t = 2 u.v
+            "v_add_f32 %9, %9, %9\n\t"                            // A
+            "v_mul_f32 %7, %2, %2\n\t"                            // M  u.u
+            "v_mul_f32 %8, %8, %12\n\t"                           // B  t u_c
+            "v_mul_f32 %9, %9, %12\n\t"                           // A
+            "v_fmac_f32 %7, %3, %3\n\t"                           // M
+            "v_fmac_f32 %8, %19, %25\n\t"                         // B  + k v_c
+            "v_fmac_f32 %9, %19, %26\n\t"                         // A
+            "v_fmac_f32 %7, %4, %4\n\t"                           // M
+            "v_fmac_f32 %8, %20, %10\n\t"                         // B  + s2 (u x v)_c
+            "v_fmac_f32 %9, %20, %11\n\t"                         // A
+            "v_fma_f32 %7, %1, %1, -%7\n\t"                       // M  k = s^2 - u.u
+            "v_mov_b32_dpp %5, %0" STAC_DPP("0,2,3,1")            // M  u_(c+1)
+            "v_mov_b32_dpp %6, %0" STAC_DPP("0,3,1,2")            // M  u_(c+2)
+            "v_add_f32 %10, %21, %8"                              // B  pcb = pc + rotate(bpos, q)
+            : "=&v"(r), "=&v"(nS), "=&v"(nUX), "=&v"(nUY), "=&v"(nUZ), "=&v"(nU1), "=&v"(nU2), "=&v"(nK), "=&v"(tB), "=&v"(tA),
+              "=&v"(mB), "=&v"(ra)
+            : "v"(Q.qc), "v"(Q.S), "v"(Q.UX), "v"(Q.UY), "v"(Q.UZ), "v"(Q.U1), "v"(Q.U2), "v"(Q.K), "v"(Q.S2), "v"(pc), "v"(Q.SX),
+              "v"(Q.SY), "v"(Q.SZ), "v"(vb), "v"(vj), "v"(ql));
+        pcb = mB;
+        ra = tA;  // (the block kept the anchor chain's cross term in `ra`)
+    } else {
+        asm("s_nop 0\n\t"
+            "v_mul_f32 %0, %11, %23\n\t"                          // M  r = s ql_c
+            "v_mul_f32_dpp %8, %22, %12" STAC_DPP("1,1,1,1")      // A  uv = jpos.x u.x
+            "v_mul_f32_dpp %9, %22, -%16" STAC_DPP("0,2,3,1")     // A  m
+            "v_fmac_f32_dpp %0, %23, %19" STAC_DPP("1,0,3,2")     // M
+            "v_fmac_f32_dpp %8, %22, %13" STAC_DPP("2,2,2,2")     // A
+            "v_fmac_f32_dpp %9, %22, %15" STAC_DPP("0,3,1,2")     // A
+            "v_fmac_f32_dpp %0, %23, %20" STAC_DPP("2,3,0,1")     // M
+            "v_fmac_f32_dpp %8, %22, %14" STAC_DPP("3,3,3,3")     // A
+            "v_fmac_f32_dpp %0, %23, %21" STAC_DPP("3,2,1,0")     // M  r = component c of q * ql
+            "v_add_f32 %8, %8, %8\n\t"                            // A  t
+            "s_nop 0\n\t"
+            "v_mov_b32_dpp %1, %0" STAC_DPP("0,0,0,0")            // M
+            "v_mov_b32_dpp %2, %0" STAC_DPP("1,1,1,1")
+            "v_mul_f32 %8, %8, %10\n\t"                           // A  t u_c
+            "v_mov_b32_dpp %3, %0" STAC_DPP("2,2,2,2")
+            "v_mov_b32_dpp %4, %0" STAC_DPP("3,3,3,3")
+            "v_fmac_f32 %8, %17, %22\n\t"                         // A  + k v_c
+            "v_mul_f32 %7, %2, %2\n\t"                            // M  u.u
+            "v_mov_b32_dpp %5, %0" STAC_DPP("0,2,3,1")
+            "v_fmac_f32 %7, %3, %3\n\t"
+            "v_fmac_f32 %8, %18, %9\n\t"                          // A  + s2 (u x v)_c
+            "v_fmac_f32 %7, %4, %4\n\t"
+            "v_mov_b32_dpp %6, %0" STAC_DPP("0,3,1,2")
+            "v_fma_f32 %7, %1, %1, -%7"                           // M  k
+            : "=&v"(r), "=&v"(nS), "=&v"(nUX), "=&v"(nUY), "=&v"(nUZ), "=&v"(nU1), "=&v"(nU2), "=&v"(nK), "=&v"(tA), "=&v"(mB)
+            : "v"(Q.qc), "v"(Q.S), "v"(Q.UX), "v"(Q.UY), "v"(Q.UZ), "v"(Q.U1), "v"(Q.U2), "v"(Q.K), "v"(Q.S2), "v"(Q.SX),
+              "v"(Q.SY), "v"(Q.SZ), "v"(vj), "v"(ql));
+        pcb = pc;
+        ra = tA;
+    }
+    Qn.qc = r; Qn.S = nS; Qn.UX = nUX; Qn.UY = nUY; Qn.UZ = nUZ; Qn.U1 = nU1; Qn.U2 = nU2; Qn.K = nK;
+}
+struct FkQuadRegs {
+    float vb, vj;  // the lane's component of bpos / jpos
+    int par_off, ja_off;
+    int4 r2;       // xf_off, ql_next, kind, aux
+    float bq;      // the lane's component of body_quat (records of 16 words)
+    float ql;      // the lane's component of the step's joint-local quaternion
+};
+struct FkQuadLane {
+    int voff;        // component offset inside a record vector: c - 1 (lane 0: 0, unused)
+    int poff, qoff;  // words of the lane's position / quaternion component inside a transform entry (lane 0 has no
+                     // position component: it aims at its quaternion word, which the quaternion store that follows overwrites)
+    int m1, m2, m3;  // sign masks of the lane's row of the quaternion product
+};
+template <int RW>
+__device__ __forceinline__ void fk_fetch_quad(FkQuadRegs &R, const float *rec, const float *CBc, const int ql_off, const FkQuadLane &L) {
+    R.vb = rec[L.voff];
+    R.vj = rec[3 + L.voff];
+    const int2 pj = *reinterpret_cast<const int2 *>(rec + 6);
+    R.par_off = pj.x;
+    R.ja_off = pj.y;
+    R.r2 = lds4i(rec + 8);
+    if constexpr (RW == 16) R.bq = rec[12 + L.qoff - kXq];
+    R.ql = CBc[ql_off - kXq + L.qoff];
+}
+// A step by its flags (any combination).  Only lanes with a position run the program (the caller masks the rest), and
+// a step stores to the sink entry what nobody reads, so nothing here is predicated per lane but the parent load.
+template <int RW>
+__device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const int mlf, float &pc, QuadQuat &Q, float *CBc,
+                                                     const float *qe, const float *jrec, const FkQuadLane &L) {
+    if (mlf & FK_ML_PARENT_LDS) {
+        float qc = Q.qc;
+        if (R.par_off >= 0) {
+            pc = CBc[R.par_off + L.poff];
+            qc = CBc[R.par_off + L.qoff];
+        }
+        quad_derive(Q, qc, L.m1, L.m2, L.m3);
+    }
+    if (mlf & FK_ML_BODY) pc = pc + quad_rotate(R.vb, Q);
+    if constexpr (RW == 16) {
+        if (mlf & FK_ML_BQUAT) quad_derive(Q, quad_qmul(Q, R.bq), L.m1, L.m2, L.m3);
+    }
+    const float pos0 = pc, prequat = Q.qc;
+    float anchor = pc;
+    if (mlf & FK_ML_SPECIAL) {  // free / slide joints somewhere in this micro-level
+        const QuadQuat Qpre = Q;
+        if (mlf & FK_ML_JOINT) {
+            if (mlf & FK_ML_JPOS) anchor = quad_rotate(R.vj, Q) + pc;
+            quad_derive(Q, quad_qmul(Q, R.ql), L.m1, L.m2, L.m3);
+            if (mlf & FK_ML_JPOS) pc = anchor - quad_rotate(R.vj, Q);
+        }
+        float qc = Q.qc;
+        const float axis = quad_rotate(jrec[12 * (R.r2.z == FK_KIND_SLIDE ? R.r2.w : 0) + 8 + L.voff], Qpre);
+        const float d = quad_dpp<0x00>(R.ql);
+        if (R.r2.z == FK_KIND_FREE) {
+            anchor = qe[R.r2.w + L.voff];
+            pc = anchor;
+            qc = R.ql;  // normalised by the pre-pass
+        } else if (R.r2.z == FK_KIND_SLIDE) {
+            qc = prequat;
+            pc = FMA(axis, d, pos0);
+        }
+        quad_derive(Q, qc, L.m1, L.m2, L.m3);
+    } else if (mlf & FK_ML_JOINT) {
+        if (mlf & FK_ML_JPOS) anchor = quad_rotate(R.vj, Q) + pc;
+        quad_derive(Q, quad_qmul(Q, R.ql), L.m1, L.m2, L.m3);
+        if (mlf & FK_ML_JPOS) pc = anchor - quad_rotate(R.vj, Q);
+    }
+    CBc[R.ja_off + L.poff] = anchor;
+    CBc[R.ja_off + L.qoff] = prequat;
+    CBc[R.r2.x + L.poff] = pc;
+    CBc[R.r2.x + L.qoff] = Q.qc;
+}
+// The frequent forms (FK_FORM_*): a hinge / ball joint with an offset on every position, with or without a body start
+template <bool BODY, bool PARENT>
+__device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, float &pc, QuadQuat &Q, float *CBc, const FkQuadLane &L) {
+    if constexpr (PARENT) {
+        const int po = R.par_off >= 0 ? R.par_off : R.r2.x;  // (any valid entry: the loaded values are dropped)
+        const float pl = CBc[po + L.poff], ql = CBc[po + L.qoff];
+        pc = R.par_off >= 0 ? pl : pc;
+        quad_derive(Q, R.par_off >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
+    }
+    float pcb, ra;
+    QuadQuat Qn;
+    quad_joint_fused<BODY>(pc, Q, R.vb, R.vj, R.ql, pcb, ra, Qn);
+    Qn.S2 = Qn.S + Qn.S;
+    Qn.SX = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UX) ^ L.m1);
+    Qn.SY = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UY) ^ L.m2);
+    Qn.SZ = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UZ) ^ L.m3);
+    const float anchor = ra + pcb;
+    CBc[R.ja_off + L.poff] = anchor;
+    CBc[R.ja_off + L.qoff] = Q.qc;
+    pc = anchor - quad_rotate(R.vj, Qn);
+    CBc[R.r2.x + L.poff] = pc;
+    CBc[R.r2.x + L.qoff] = Qn.qc;
+    Q = Qn;
+}
+template <int RW>
+__device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, const int code, float &pc,
+                                             QuadQuat &Q, float *CBc, const float *qe, const float *jrec, const FkQuadLane &L) {
+    fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+    const int form = code >> 8;
+    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<true, false>(R, pc, Q, CBc, L);
+    else if (form == FK_FORM_JOINT) fk_step_quad_joint<false, false>(R, pc, Q, CBc, L);
+    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<true, true>(R, pc, Q, CBc, L);
+    else fk_step_quad_general<RW>(R, code & 255, pc, Q, CBc, qe, jrec, L);
+    wave_sync();
+}
+template <int RW>
+__device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                                const bool active, const int prog_off, const int n_ml) {
+    const int W = H.max_width;
+    const int pp = lf >> 2, c = lf & 3;
+    if (!(active && pp < W)) return;  // whole quads: the DPP operands below stay inside a quad
+    FkQuadLane L;
+    L.voff = c ? c - 1 : 0;
+    L.poff = c ? c - 1 : kXq;
+    L.qoff = kXq + c;
+    const int sgn = (int)0x80000000u;
+    L.m1 = (c == 0 || c == 2) ? sgn : 0;
+    L.m2 = (c == 0 || c == 3) ? sgn : 0;
+    L.m3 = (c == 0 || c == 1) ? sgn : 0;
+    const int *hdr = reinterpret_cast<const int *>(P + prog_off);
+    const float *sp = P + prog_off + H.fk_hdr_words + RW * pp;
+    const float *jrec = P + H.off_joint;
+    const float *qe = CBc + H.c_qe;
+    float pc = 0.f;
+    QuadQuat Q;
+    quad_derive(Q, c == 0 ? 1.f : 0.f, L.m1, L.m2, L.m3);
+    FkQuadRegs A, B;
+    A.bq = B.bq = c == 0 ? 1.f : 0.f;
+    fk_fetch_quad<RW>(A, sp, CBc, hdr[(H.n_mlev_hdr >> 1) + pp], L);
+    const int stride = RW * W;
+    int fl_v = hdr[0];
+    for (int ml = 0; ml < n_ml; ml += 2) {
+        const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+        fl_v = hdr[(ml >> 1) + 1];
+        sp += stride;
+        fk_step_quad<RW>(A, B, sp, fl & 0xFFFF, pc, Q, CBc, qe, jrec, L);
+        if (ml + 2 < n_ml) sp += stride;
+        fk_step_quad<RW>(B, A, sp, (fl >> 16) & 0xFFFF, pc, Q, CBc, qe, jrec, L);
+    }
+}
+
+// FK of one chain by gf lanes: the program when every level fits the lanes (four lanes per position when QUAD and
+// they fit four times over), else the level loop.
 // n_ml_root > 0 (wave-uniform): every chain of the wavefront is in a root pass -- run the pruned program at off_fkroot.
+template <bool QUAD>
 __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
                                          const bool active, const bool store_ja, const bool use_levels,
                                          const int n_ml_root = 0) {
     if (H.max_width <= gf && !use_levels) {
         const int prog_off = n_ml_root > 0 ? H.off_fkroot : H.off_fkstep;
         const int n_ml = n_ml_root > 0 ? n_ml_root : H.n_mlev;
+        if constexpr (QUAD) {
+            if (4 * H.max_width <= gf) {
+                if (H.fk_rec_words == 16) fk_program_quad<16>(H, P, CBc, lf, gf, active, prog_off, n_ml);
+                else fk_program_quad<12>(H, P, CBc, lf, gf, active, prog_off, n_ml);
+                return;
+            }
+#ifdef STAC_QUAD_ONLY
+            fk_levels(H, P, CBc, lf, gf, active, store_ja);
+            return;
+#endif
+        }
         if (H.fk_rec_words == 16) fk_program<16>(H, P, CBc, lf, gf, active, store_ja, prog_off, n_ml);
         else fk_program<12>(H, P, CBc, lf, gf, active, store_ja, prog_off, n_ml);
     } else {

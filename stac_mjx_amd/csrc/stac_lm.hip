@@ -154,7 +154,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
         // ---- forward kinematics: the PG kernel's joint-local pre-pass + FK program (stac_device.hpp) -------------------
         joint_local_prepass(H, P, CB, lg, G);
         wave_sync();
-        fk_chain(H, P, CB, lg, G, true, true, (a.flags & 2) != 0);
+        fk_chain<(G >= 16)>(H, P, CB, lg, G, true, true, (a.flags & 2) != 0);
 
         PROF_TICK(1);  // stage + FK
         // ---- sites: world position (kept for the Jacobian), residual, loss term, wrench -------------------------------

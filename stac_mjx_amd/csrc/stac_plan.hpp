@@ -69,11 +69,11 @@ struct RangeRec { int32_t lo, hi; };
 // common step has no divergent branch and no select.  All offsets are word offsets into the chain's LDS region.
 struct FkStep {       // 12 words (+4 when some active body has a non-identity body_quat)
     float bpos[3];    // body_pos, or zeros
+    float jpos[3];    // jnt_pos, or zeros
     int32_t par_off;  // transform of the parent (c_bx + kXf * index) when another lane produced it, else -1 (the
                       // lane's running transform is the parent's)
-    float jpos[3];    // jnt_pos, or zeros
-    int32_t ja_off;   // this joint's anchor / pre-joint quaternion entry (c_ja + kXf * j), -1 = no joint in this step
-    int32_t xf_off;   // where the body's transform goes after this step (c_bx + kXf * index), -1 = not stored
+    int32_t ja_off;   // this joint's anchor / pre-joint quaternion entry (c_ja + kXf * j); no joint in this step: c_sink
+    int32_t xf_off;   // where the body's transform goes after this step (c_bx + kXf * index); not stored: c_sink
     int32_t ql_next;  // joint-local quaternion of this position's NEXT step (fetched one step ahead), or the
                       // identity quaternion of the world entry (c_bx + kXq)
     int32_t kind;     // FK_KIND_*
@@ -89,6 +89,15 @@ enum : int32_t {
     FK_ML_JOINT = 8,       // ... has a joint (else the whole joint part is skipped)
     FK_ML_JPOS = 16,       // ... has a joint with jnt_pos != 0 (else anchor = pos and pos stays: exact)
     FK_ML_BQUAT = 32,      // ... starts a body with a non-identity body_quat
+};
+
+// The form of a micro-level's step, next to its flags (flags | form << 8, 16 bits per micro-level): the frequent flag
+// combinations run as straight-line code.
+enum : int32_t {
+    FK_FORM_GENERAL = 0,            // by the flags
+    FK_FORM_BODY_JOINT = 1,         // BODY | JOINT | JPOS: every position composes with a parent it holds and applies a joint
+    FK_FORM_JOINT = 2,              // JOINT | JPOS: further joints of the bodies
+    FK_FORM_PARENT_BODY_JOINT = 3,  // as BODY_JOINT, some parents come from LDS
 };
 
 struct SiteRec {      // 4 words
@@ -120,6 +129,8 @@ struct PlanHeader {
     int32_t c_ja;      // [naj*kXf] anchor + quaternion before the joint (the joint pass rotates the axis)
     int32_t c_jn;      // [nqj] |q| of the active free / ball quaternions, by quaternion ordinal (JointRec::q0)
     int32_t c_sw;      // [K*kXf] site wrench entries {f(3), -, t(3), -} by sorted-site position
+    int32_t c_sink;    // one entry at the tail of the site-wrench region, dead during the kinematics: where the FK program's
+                       // steps store what nobody reads (instead of predicating the store)
     int32_t c_gg;      // [nqpad] gradient out: the site-wrench region (dead once the range sums are done)
     int32_t c_rw;      // [nrange*kXf] wrench sums of the distinct ranges {F(3), -, T(3), -}: the body-transform region
                        // when they fit (the transforms are dead once the sites have read them), else an own region
@@ -134,7 +145,7 @@ struct PlanHeader {
     int32_t nqj;       // active quaternion joints (free / ball)
     int32_t kpow2;     // K rounded up to a power of two (the LDS loss tree of models with more than 64 sites)
     int32_t c_qsv;     // [4*nqj] their normalised quaternions, kept for the gradient pass
-    int32_t off_fkstep;    // header (fk_hdr_words: one word per PAIR of micro-levels (FK_ML_* of step ml | FK_ML_* of step ml + 1 << 8), then the ql offset of
+    int32_t off_fkstep;    // header (fk_hdr_words: one word per PAIR of micro-levels (FK_ML_* | FK_FORM_* << 8 of step ml, the same of step ml + 1 << 16), then the ql offset of
                            // each position's first step), then FkStep[n_mlev * max_width] (word offset into the blob)
     int32_t off_fkroot;    // same size: the pruned program of the root passes (filled per call from the trunk keypoints)
     int32_t fk_hdr_words;  // words in front of the records of either program
