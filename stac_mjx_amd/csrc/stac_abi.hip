@@ -158,14 +158,21 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     const PlanHeader &h = m->h;
     const int W = h.max_width, rw = h.fk_rec_words, nlev = h.nlev, hw = h.fk_hdr_words;
     const std::vector<int> &lev_adr = m->h_lev_adr;
-    std::vector<int> mfirst(nlev + 1, 0);
-    for (int l = 0; l < nlev; ++l) {
-        int mm = 0;
-        for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s)
-            if (!need || need[s]) mm = std::max(mm, std::max(1, m->h_ab_jnum[s]));
-        mfirst[l + 1] = mfirst[l] + mm;
-    }
-    const int n_mlev = std::max((mfirst[nlev] + 1) & ~1, 2);  // even: the kernel runs two steps per loop trip
+    // Start step of every body: as soon as its parent is finished and its lane position is free (positions are those of
+    // the level layout, so a position runs its bodies in level order and a child that takes over its parent's position
+    // starts in the step after the parent's last).  A level no longer waits for its slowest body.
+    std::vector<int> tstart(m->h_brec.size(), 0), tfin(m->h_brec.size(), 0), free_t(W, 0);
+    int t_end = 0;
+    for (int l = 0; l < nlev; ++l)
+        for (int s = lev_adr[l]; s < lev_adr[l + 1]; ++s) {
+            if (need && !need[s]) continue;
+            const int pp = s - lev_adr[l], ps = m->h_ab_parent[s];  // parent slot + 1, 0 = world
+            tstart[s] = std::max(ps ? tfin[ps - 1] : 0, free_t[pp]);
+            tfin[s] = tstart[s] + std::max(1, m->h_ab_jnum[s]);
+            free_t[pp] = tfin[s];
+            t_end = std::max(t_end, tfin[s]);
+        }
+    const int n_mlev = std::max((t_end + 1) & ~1, 2);  // even: the kernel runs two steps per loop trip
     auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
     const int32_t ident_ql = h.c_bx + kXq;  // the world entry's quaternion (1, 0, 0, 0)
     std::vector<int32_t> prog((size_t)hw + (size_t)n_mlev * W * rw, 0);
@@ -182,7 +189,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
             const BodyRec &br = m->h_brec[s];
             const int pp = s - lev_adr[l], njs = m->h_ab_jnum[s], nsteps = std::max(1, njs), xfs = m->h_xf[s];
             for (int i = 0; i < nsteps; ++i) {
-                const int ml = mfirst[l] + i;
+                const int ml = tstart[s] + i;
                 int32_t *r = prog.data() + hw + ((size_t)ml * W + pp) * rw;
                 const int fsh = 16 * (ml & 1);
                 if (i == 0) {
@@ -218,8 +225,22 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
         if ((fl & (FK_ML_JOINT | FK_ML_JPOS | FK_ML_SPECIAL | FK_ML_BQUAT)) == (FK_ML_JOINT | FK_ML_JPOS)) {
             if (!(fl & FK_ML_PARENT_LDS)) form = (fl & FK_ML_BODY) ? FK_FORM_BODY_JOINT : FK_FORM_JOINT;
             else if (fl & FK_ML_BODY) form = FK_FORM_PARENT_BODY_JOINT;
+        } else if (fl == 0) {
+            form = FK_FORM_IDLE;
+        } else if (fl == FK_ML_BODY) {
+            form = FK_FORM_BODY;
+        } else if (fl == (FK_ML_BODY | FK_ML_PARENT_LDS)) {
+            form = FK_FORM_PARENT_BODY;
+        } else if ((fl & (FK_ML_JOINT | FK_ML_JPOS | FK_ML_SPECIAL | FK_ML_BQUAT)) == FK_ML_JOINT) {
+            if (!(fl & FK_ML_PARENT_LDS)) form = (fl & FK_ML_BODY) ? FK_FORM_BODY_QJOINT : FK_FORM_QJOINT;
+            else if (fl & FK_ML_BODY) form = FK_FORM_PARENT_BODY_QJOINT;
         }
         prog[ml >> 1] |= form << (fsh + 8);
+    }
+    if (m->dbg.verbose) {
+        fprintf(stderr, "[stac] FK program%s: %d steps, forms", need ? " (root passes)" : "", n_mlev);
+        for (int ml = 0; ml < n_mlev; ++ml) fprintf(stderr, " %d(%x)", (prog[ml >> 1] >> (16 * (ml & 1) + 8)) & 255, (prog[ml >> 1] >> (16 * (ml & 1))) & 255);
+        fprintf(stderr, "\n");
     }
     *n_mlev_out = n_mlev;
     return prog;

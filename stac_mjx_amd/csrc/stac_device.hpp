@@ -616,39 +616,83 @@ __device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const 
     CBc[R.r2.x + L.poff] = pc;
     CBc[R.r2.x + L.qoff] = Q.qc;
 }
-// The frequent forms (FK_FORM_*): a hinge / ball joint with an offset on every position, with or without a body start
-template <bool BODY, bool PARENT>
-__device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, float &pc, QuadQuat &Q, float *CBc, const FkQuadLane &L) {
+// The frequent forms (FK_FORM_*), straight-line.  JPOS: hinge / ball joints with an offset (jnt_pos != 0) -- else the
+// anchor is the body position and the position stays (exact).  BODY: the step starts bodies.  PARENT: some of them load
+// their parent's transform (issued ahead of the next record's fetch: the loads return in order).
+template <int RW, bool JPOS, bool BODY, bool PARENT>
+__device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, float &pc, QuadQuat &Q,
+                                                   float *CBc, const FkQuadLane &L) {
     if constexpr (PARENT) {
         const int po = R.par_off >= 0 ? R.par_off : R.r2.x;  // (any valid entry: the loaded values are dropped)
         const float pl = CBc[po + L.poff], ql = CBc[po + L.qoff];
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
         pc = R.par_off >= 0 ? pl : pc;
         quad_derive(Q, R.par_off >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
+    } else {
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
     }
     float pcb, ra;
     QuadQuat Qn;
-    quad_joint_fused<BODY>(pc, Q, R.vb, R.vj, R.ql, pcb, ra, Qn);
-    Qn.S2 = Qn.S + Qn.S;
-    Qn.SX = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UX) ^ L.m1);
-    Qn.SY = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UY) ^ L.m2);
-    Qn.SZ = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UZ) ^ L.m3);
-    const float anchor = ra + pcb;
+    if constexpr (JPOS) {
+        quad_joint_fused<BODY>(pc, Q, R.vb, R.vj, R.ql, pcb, ra, Qn);
+    } else if constexpr (BODY) {
+        quad_joint_fused<false>(pc, Q, R.vb, R.vb, R.ql, pcb, ra, Qn);  // the same block: rotate(bpos, q) beside q * ql
+        pcb = pc + ra;
+    } else {
+        Qn.qc = quad_qmul(Q, R.ql);
+    }
+    if constexpr (JPOS || BODY) {
+        Qn.S2 = Qn.S + Qn.S;
+        Qn.SX = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UX) ^ L.m1);
+        Qn.SY = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UY) ^ L.m2);
+        Qn.SZ = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UZ) ^ L.m3);
+    } else {
+        pcb = pc;
+        quad_derive(Qn, Qn.qc, L.m1, L.m2, L.m3);
+    }
+    const float anchor = JPOS ? ra + pcb : pcb;
     CBc[R.ja_off + L.poff] = anchor;
     CBc[R.ja_off + L.qoff] = Q.qc;
-    pc = anchor - quad_rotate(R.vj, Qn);
+    if constexpr (JPOS) pc = anchor - quad_rotate(R.vj, Qn);
+    else pc = pcb;
     CBc[R.r2.x + L.poff] = pc;
     CBc[R.r2.x + L.qoff] = Qn.qc;
     Q = Qn;
 }
+// a step that only starts bodies (no position has a joint in it)
+template <int RW, bool PARENT>
+__device__ __forceinline__ void fk_step_quad_body(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, float &pc, QuadQuat &Q,
+                                                  float *CBc, const FkQuadLane &L) {
+    if constexpr (PARENT) {
+        const int po = R.par_off >= 0 ? R.par_off : R.r2.x;
+        const float pl = CBc[po + L.poff], ql = CBc[po + L.qoff];
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+        pc = R.par_off >= 0 ? pl : pc;
+        quad_derive(Q, R.par_off >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
+    } else {
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+    }
+    pc = pc + quad_rotate(R.vb, Q);
+    CBc[R.r2.x + L.poff] = pc;
+    CBc[R.r2.x + L.qoff] = Q.qc;
+}
 template <int RW>
 __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, const int code, float &pc,
                                              QuadQuat &Q, float *CBc, const float *qe, const float *jrec, const FkQuadLane &L) {
-    fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
     const int form = code >> 8;
-    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<true, false>(R, pc, Q, CBc, L);
-    else if (form == FK_FORM_JOINT) fk_step_quad_joint<false, false>(R, pc, Q, CBc, L);
-    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<true, true>(R, pc, Q, CBc, L);
-    else fk_step_quad_general<RW>(R, code & 255, pc, Q, CBc, qe, jrec, L);
+    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, true, true, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_JOINT) fk_step_quad_joint<RW, true, false, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<RW, true, true, true>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_BODY_QJOINT) fk_step_quad_joint<RW, false, true, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_QJOINT) fk_step_quad_joint<RW, false, false, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_PARENT_BODY_QJOINT) fk_step_quad_joint<RW, false, true, true>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_BODY) fk_step_quad_body<RW, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_PARENT_BODY) fk_step_quad_body<RW, true>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_IDLE) fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+    else {
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+        fk_step_quad_general<RW>(R, code & 255, pc, Q, CBc, qe, jrec, L);
+    }
     wave_sync();
 }
 template <int RW>

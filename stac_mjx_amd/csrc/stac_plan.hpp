@@ -98,6 +98,12 @@ enum : int32_t {
     FK_FORM_BODY_JOINT = 1,         // BODY | JOINT | JPOS: every position composes with a parent it holds and applies a joint
     FK_FORM_JOINT = 2,              // JOINT | JPOS: further joints of the bodies
     FK_FORM_PARENT_BODY_JOINT = 3,  // as BODY_JOINT, some parents come from LDS
+    FK_FORM_BODY_QJOINT = 4,        // BODY | JOINT with jnt_pos = 0 everywhere (anchor = position, which stays)
+    FK_FORM_QJOINT = 5,             // JOINT alone, jnt_pos = 0
+    FK_FORM_PARENT_BODY_QJOINT = 6,
+    FK_FORM_IDLE = 7,               // nothing (padding step)
+    FK_FORM_BODY = 8,               // BODY alone: bodies without a joint
+    FK_FORM_PARENT_BODY = 9,
 };
 
 struct SiteRec {      // 4 words
