@@ -297,7 +297,7 @@ def main():
             "frames_per_s": Cc * Fc / (c_ms * 1e-3), "kernel_ms": c_ms,
             "iters_per_frame": ccnt[0] / (Cc * Fc), "us_per_pg_iteration": c_ms * 1e3 / (ccnt[0] / Cc),
             "marker_rmse_mm": float(torch.sqrt((cerr ** 2).mean()).item() * 1e3),
-            "note": "each clip is one serial chain of 250 x ~410 PG iterations: speculative latency mode, 8 wavefronts per chain"}
+            "note": "each clip is one serial chain of 250 x ~410 PG iterations: speculative latency mode, 4 wavefronts per chain"}
     if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and not args.no_extras:
         # the north star words the q_phase as a Levenberg-Marquardt update; the reference runs projected gradient (the
         # `value` above, parity mode).  The optional LM solver on the same resident batch, for the record -- never `value`.
