@@ -179,7 +179,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     for (int ml = 0; ml < n_mlev; ++ml)
         for (int pp = 0; pp < W; ++pp) {  // a position without work: neutral data, nothing stored
             int32_t *r = prog.data() + hw + ((size_t)ml * W + pp) * rw;
-            r[6] = -1; r[7] = h.c_sink; r[8] = h.c_sink; r[9] = ident_ql; r[10] = FK_KIND_PLAIN;
+            r[4] = -1; r[5] = h.c_sink; r[6] = h.c_sink; r[7] = ident_ql; r[3] = FK_KIND_PLAIN;
             if (rw == 16) r[12] = f2i(1.0f);
         }
     std::vector<int32_t> ql_of((size_t)n_mlev * W, ident_ql);  // ql offset of every (micro-level, position)
@@ -196,7 +196,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
                     prog[ml >> 1] |= FK_ML_BODY << fsh;
                     if (!(br.flags & 1)) prog[ml >> 1] |= FK_ML_BQUAT << fsh;
                     if (!(br.flags & 2)) {  // the parent's transform comes from LDS (another lane produced it, or the world)
-                        r[6] = h.c_bx + kXf * br.parent;
+                        r[4] = h.c_bx + kXf * br.parent;
                         prog[ml >> 1] |= FK_ML_PARENT_LDS << fsh;
                     }
                     for (int c = 0; c < 3; ++c) r[c] = f2i(br.pos[c]);
@@ -205,19 +205,19 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
                 if (i < njs) {
                     const int j = m->h_ab_jadr[s] + i, ty = m->h_aj_type[j];
                     const float *jp = m->h_aj_pos.data() + 3 * j;
-                    for (int c = 0; c < 3; ++c) r[3 + c] = f2i(jp[c]);
-                    r[7] = h.c_ja + kXf * j;
+                    for (int c = 0; c < 3; ++c) r[8 + c] = f2i(jp[c]);
+                    r[5] = h.c_ja + kXf * j;
                     ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + kXq;
                     prog[ml >> 1] |= FK_ML_JOINT << fsh;
                     if (jp[0] != 0.0f || jp[1] != 0.0f || jp[2] != 0.0f) prog[ml >> 1] |= FK_ML_JPOS << fsh;
-                    if (ty == STAC_JNT_FREE) { r[10] = FK_KIND_FREE; r[11] = m->h_aj_qadr[j]; prog[ml >> 1] |= FK_ML_SPECIAL << fsh; }
-                    if (ty == STAC_JNT_SLIDE) { r[10] = FK_KIND_SLIDE; r[11] = j; prog[ml >> 1] |= (FK_ML_SPECIAL | FK_ML_JPOS) << fsh; }
+                    if (ty == STAC_JNT_FREE) { r[3] = FK_KIND_FREE; r[11] = m->h_aj_qadr[j]; prog[ml >> 1] |= FK_ML_SPECIAL << fsh; }
+                    if (ty == STAC_JNT_SLIDE) { r[3] = FK_KIND_SLIDE; r[11] = j; prog[ml >> 1] |= (FK_ML_SPECIAL | FK_ML_JPOS) << fsh; }
                 }
-                if (i == nsteps - 1 && xfs >= 0) r[8] = h.c_bx + kXf * xfs;
+                if (i == nsteps - 1 && xfs >= 0) r[6] = h.c_bx + kXf * xfs;
             }
         }
     for (int ml = 0; ml + 1 < n_mlev; ++ml)
-        for (int pp = 0; pp < W; ++pp) prog[hw + ((size_t)ml * W + pp) * rw + 9] = ql_of[(size_t)(ml + 1) * W + pp];
+        for (int pp = 0; pp < W; ++pp) prog[hw + ((size_t)ml * W + pp) * rw + 7] = ql_of[(size_t)(ml + 1) * W + pp];
     for (int pp = 0; pp < W; ++pp) prog[(h.n_mlev_hdr >> 1) + pp] = ql_of[pp];  // first steps: fetched by the prologue
     for (int ml = 0; ml < n_mlev; ++ml) {  // step form (FK_FORM_*) next to the flags
         const int fsh = 16 * (ml & 1), fl = (prog[ml >> 1] >> fsh) & 255;

@@ -146,22 +146,22 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ int4 lds4i(const float *p) { return *reinterpret_cast<const int4 *>(p); }
-// transform entries (kXf words, 16-byte aligned: stac_plan.hpp): position in words 0-2, quaternion in words 4-7
+// transform entries (kXf words: stac_plan.hpp): position in words 0-2, quaternion (x, y, z, w) in words kXq .. kXq + 3
 __device__ __forceinline__ V3 ld_tpos(const float *p) {
     if constexpr (kXf == 8) { const float4 v = lds4(p); return {v.x, v.y, v.z}; }
     else return ld3(p);
 }
 __device__ __forceinline__ Q4 ld_tquat(const float *p) {
-    if constexpr (kXf == 8) { const float4 v = lds4(p + 4); return {v.x, v.y, v.z, v.w}; }
-    else return ld4(p + 3);
+    if constexpr (kXf == 8) { const float4 v = lds4(p + 4); return {v.w, v.x, v.y, v.z}; }
+    else return {p[6], p[3], p[4], p[5]};
 }
 __device__ __forceinline__ void st_tpos(float *p, V3 v) {
     if constexpr (kXf == 8) *reinterpret_cast<float4 *>(p) = float4{v.x, v.y, v.z, 0.0f};
     else st3(p, v);
 }
 __device__ __forceinline__ void st_tquat(float *p, Q4 q) {
-    if constexpr (kXf == 8) *reinterpret_cast<float4 *>(p + 4) = float4{q.w, q.x, q.y, q.z};
-    else st4(p + 3, q);
+    if constexpr (kXf == 8) *reinterpret_cast<float4 *>(p + 4) = float4{q.x, q.y, q.z, q.w};
+    else { p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w; }
 }
 // second vector of a wrench entry {f, t}
 __device__ __forceinline__ V3 ld_tvec2(const float *p) { return ld_tpos(p + kXq); }
@@ -190,7 +190,7 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
             st_tquat(ja + kXf * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
         } else if (ty == JSLIDE) {
             const float4 jp4 = lds4(jr + 4);
-            ja[kXf * j + kXq] = qe[ad] - jp4.w;
+            ja[kXf * j + kXw] = qe[ad] - jp4.w;  // (the w word of the entry's quaternion)
         } else {
             const int qa = ty == JFREE ? ad + 3 : ad;
             float n;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
                     if (!jzero) anchor = add3(rotate(jp, quat), pos);
                     const float4 ja4 = lds4(jr + 8);
                     const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, quat);
-                    const float d = ja[kXf * j + kXq];
+                    const float d = ja[kXf * j + kXw];
                     pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
                 }
                 if (store_ja) {
@@ -292,17 +292,17 @@ __device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, f
 // per-micro-level flag word (wave-uniform) says when some position needs a parent that another lane produced or has
 // a free / slide joint.  Requires max_width <= gf.  Bit-identical to fk_levels.
 struct FkRegs {
-    float4 r0;  // bpos | jpos.x
-    float4 r1;  // jpos.yz | par_off, ja_off
-    int4 r2;    // xf_off, ql_next, kind, aux
+    float4 r0;  // bpos | kind
+    int4 r1;    // par_off, ja_off, xf_off, ql_next
+    float4 r2;  // jpos | aux
     float4 r3;  // body_quat (records of 16 words)
     Q4 ql;      // joint-local quaternion of the step's joint (identity: none)
 };
 template <int RW>
 __device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const float *CBc, const int ql_off) {
     R.r0 = lds4(rec);
-    R.r1 = lds4(rec + 4);
-    R.r2 = lds4i(rec + 8);
+    R.r1 = lds4i(rec + 4);
+    R.r2 = lds4(rec + 8);
     if constexpr (RW == 16) R.r3 = lds4(rec + 12);
     R.ql = ld_tquat(CBc + ql_off - kXq);  // ql_off = the quaternion words of a transform entry
 }
@@ -311,9 +311,9 @@ __device__ __forceinline__ void fk_fetch(FkRegs &R, const float *rec, const floa
 template <int RW>
 __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float *next_rec, const int mlf, const bool on,
                                         V3 &pos, Q4 &quat, float *CBc, const float *qe, const float *jrec, const bool store_ja) {
-    fk_fetch<RW>(N, next_rec, CBc, R.r2.y);
+    fk_fetch<RW>(N, next_rec, CBc, R.r1.w);
     if (mlf & FK_ML_PARENT_LDS) {  // wave-uniform: some position starts a body whose parent another lane (or nobody) produced
-        const int po = __builtin_bit_cast(int, R.r1.z);
+        const int po = R.r1.x;
         if (on && po >= 0) {
             pos = ld_tpos(CBc + po);
             quat = ld_tquat(CBc + po);
@@ -325,7 +325,7 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
     if constexpr (RW == 16) {
         if (mlf & FK_ML_BQUAT) quat = qmul(quat, Q4{R.r3.x, R.r3.y, R.r3.z, R.r3.w});
     }
-    const V3 jp = {R.r0.w, R.r1.x, R.r1.y};
+    const V3 jp = {R.r2.x, R.r2.y, R.r2.z};
     const V3 pos0 = pos;
     const Q4 prequat = quat;  // xaxis = rotate(jnt_axis, prequat) is evaluated by the joint pass
     V3 anchor = pos;
@@ -335,26 +335,26 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
         if (mlf & FK_ML_JPOS) pos = sub3(anchor, rotate(jp, quat));
     }
     if (mlf & FK_ML_SPECIAL) {  // wave-uniform: some position has a free or a slide joint in this micro-level
-        if (on && R.r2.z == FK_KIND_FREE) {
-            anchor = ld3(qe + R.r2.w);
+        const int kind = __builtin_bit_cast(int, R.r0.w), aux = __builtin_bit_cast(int, R.r2.w);
+        if (on && kind == FK_KIND_FREE) {
+            anchor = ld3(qe + aux);
             pos = anchor;
             quat = R.ql;  // normalised by the pre-pass
-        } else if (on && R.r2.z == FK_KIND_SLIDE) {
-            const float4 ja4 = lds4(jrec + 12 * R.r2.w + 8);
+        } else if (on && kind == FK_KIND_SLIDE) {
+            const float4 ja4 = lds4(jrec + 12 * aux + 8);
             const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, prequat);
             const float d = R.ql.w;
             quat = prequat;
             pos = {FMA(axis.x, d, pos0.x), FMA(axis.y, d, pos0.y), FMA(axis.z, d, pos0.z)};
         }
     }
-    const int jo = __builtin_bit_cast(int, R.r1.w);
     if (store_ja && on) {  // (a step without a joint aims at the sink entry)
-        st_tpos(CBc + jo, anchor);
-        st_tquat(CBc + jo, prequat);
+        st_tpos(CBc + R.r1.y, anchor);
+        st_tquat(CBc + R.r1.y, prequat);
     }
     if (on) {
-        st_tpos(CBc + R.r2.x, pos);
-        st_tquat(CBc + R.r2.x, quat);
+        st_tpos(CBc + R.r1.z, pos);
+        st_tquat(CBc + R.r1.z, quat);
     }
     wave_sync();
 }
@@ -546,38 +546,43 @@ __device__ __forceinline__ void quad_joint_fused(const float pc, const QuadQuat 
 }
 struct FkQuadRegs {
     float vb, vj;  // the lane's component of bpos / jpos
-    int par_off, ja_off;
-    int4 r2;       // xf_off, ql_next, kind, aux
+    int4 o;        // par_off, ja_off, xf_off, ql_next
     float bq;      // the lane's component of body_quat (records of 16 words)
     float ql;      // the lane's component of the step's joint-local quaternion
 };
 struct FkQuadLane {
+    int c;           // 0 .. 3 = w, x, y, z
     int voff;        // component offset inside a record vector: c - 1 (lane 0: 0, unused)
-    int poff, qoff;  // words of the lane's position / quaternion component inside a transform entry (lane 0 has no
-                     // position component: it aims at its quaternion word, which the quaternion store that follows overwrites)
+    int poff;        // word of the lane's position component inside a transform entry; its quaternion component is kXq
+                     // words behind (entries hold x, y, z, w).  Lane 0 has no position component: it aims at word 3,
+                     // which the quaternion half of the same ds_write2_b32 -- lane 1's x, or its own w with padded
+                     // entries -- overwrites (data0 of all lanes is written before data1: build/micro/w2order.hip)
     int m1, m2, m3;  // sign masks of the lane's row of the quaternion product
 };
+// {position component, quaternion component} of the lane into the entry at word offset `off`: one LDS instruction
+__device__ __forceinline__ void quad_store(float *CBc, const int off, const FkQuadLane &L, const float p, const float q) {
+    const unsigned adr = (unsigned)(size_t)(CBc + off + L.poff);
+    if constexpr (kXq == 3) asm volatile("ds_write2_b32 %0, %1, %2 offset1:3" ::"v"(adr), "v"(p), "v"(q) : "memory");
+    else asm volatile("ds_write2_b32 %0, %1, %2 offset1:4" ::"v"(adr), "v"(p), "v"(q) : "memory");
+}
 template <int RW>
 __device__ __forceinline__ void fk_fetch_quad(FkQuadRegs &R, const float *rec, const float *CBc, const int ql_off, const FkQuadLane &L) {
     R.vb = rec[L.voff];
-    R.vj = rec[3 + L.voff];
-    const int2 pj = *reinterpret_cast<const int2 *>(rec + 6);
-    R.par_off = pj.x;
-    R.ja_off = pj.y;
-    R.r2 = lds4i(rec + 8);
-    if constexpr (RW == 16) R.bq = rec[12 + L.qoff - kXq];
-    R.ql = CBc[ql_off - kXq + L.qoff];
+    R.vj = rec[8 + L.voff];
+    R.o = lds4i(rec + 4);
+    if constexpr (RW == 16) R.bq = rec[12 + L.c];
+    R.ql = CBc[ql_off + L.poff];  // (ql_off = the quaternion words x, y, z, w of an entry)
 }
 // A step by its flags (any combination).  Only lanes with a position run the program (the caller masks the rest), and
 // a step stores to the sink entry what nobody reads, so nothing here is predicated per lane but the parent load.
 template <int RW>
-__device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const int mlf, float &pc, QuadQuat &Q, float *CBc,
-                                                     const float *qe, const float *jrec, const FkQuadLane &L) {
+__device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const float *rec, const int mlf, float &pc, QuadQuat &Q,
+                                                     float *CBc, const float *qe, const float *jrec, const FkQuadLane &L) {
     if (mlf & FK_ML_PARENT_LDS) {
         float qc = Q.qc;
-        if (R.par_off >= 0) {
-            pc = CBc[R.par_off + L.poff];
-            qc = CBc[R.par_off + L.qoff];
+        if (R.o.x >= 0) {
+            pc = CBc[R.o.x + L.poff];
+            qc = CBc[R.o.x + L.poff + kXq];
         }
         quad_derive(Q, qc, L.m1, L.m2, L.m3);
     }
@@ -595,13 +600,14 @@ __device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const 
             if (mlf & FK_ML_JPOS) pc = anchor - quad_rotate(R.vj, Q);
         }
         float qc = Q.qc;
-        const float axis = quad_rotate(jrec[12 * (R.r2.z == FK_KIND_SLIDE ? R.r2.w : 0) + 8 + L.voff], Qpre);
+        const int kind = __builtin_bit_cast(int, rec[3]), aux = __builtin_bit_cast(int, rec[11]);  // (not part of the prefetch)
+        const float axis = quad_rotate(jrec[12 * (kind == FK_KIND_SLIDE ? aux : 0) + 8 + L.voff], Qpre);
         const float d = quad_dpp<0x00>(R.ql);
-        if (R.r2.z == FK_KIND_FREE) {
-            anchor = qe[R.r2.w + L.voff];
+        if (kind == FK_KIND_FREE) {
+            anchor = qe[aux + L.voff];
             pc = anchor;
             qc = R.ql;  // normalised by the pre-pass
-        } else if (R.r2.z == FK_KIND_SLIDE) {
+        } else if (kind == FK_KIND_SLIDE) {
             qc = prequat;
             pc = FMA(axis, d, pos0);
         }
@@ -611,10 +617,8 @@ __device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const 
         quad_derive(Q, quad_qmul(Q, R.ql), L.m1, L.m2, L.m3);
         if (mlf & FK_ML_JPOS) pc = anchor - quad_rotate(R.vj, Q);
     }
-    CBc[R.ja_off + L.poff] = anchor;
-    CBc[R.ja_off + L.qoff] = prequat;
-    CBc[R.r2.x + L.poff] = pc;
-    CBc[R.r2.x + L.qoff] = Q.qc;
+    quad_store(CBc, R.o.y, L, anchor, prequat);
+    quad_store(CBc, R.o.z, L, pc, Q.qc);
 }
 // The frequent forms (FK_FORM_*), straight-line.  JPOS: hinge / ball joints with an offset (jnt_pos != 0) -- else the
 // anchor is the body position and the position stays (exact).  BODY: the step starts bodies.  PARENT: some of them load
@@ -623,13 +627,13 @@ template <int RW, bool JPOS, bool BODY, bool PARENT>
 __device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, float &pc, QuadQuat &Q,
                                                    float *CBc, const FkQuadLane &L) {
     if constexpr (PARENT) {
-        const int po = R.par_off >= 0 ? R.par_off : R.r2.x;  // (any valid entry: the loaded values are dropped)
-        const float pl = CBc[po + L.poff], ql = CBc[po + L.qoff];
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
-        pc = R.par_off >= 0 ? pl : pc;
-        quad_derive(Q, R.par_off >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
+        const int po = R.o.x >= 0 ? R.o.x : R.o.z;  // (any valid entry: the loaded values are dropped)
+        const float pl = CBc[po + L.poff], ql = CBc[po + L.poff + kXq];
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
+        pc = R.o.x >= 0 ? pl : pc;
+        quad_derive(Q, R.o.x >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
     } else {
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
     }
     float pcb, ra;
     QuadQuat Qn;
@@ -651,12 +655,10 @@ __device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRe
         quad_derive(Qn, Qn.qc, L.m1, L.m2, L.m3);
     }
     const float anchor = JPOS ? ra + pcb : pcb;
-    CBc[R.ja_off + L.poff] = anchor;
-    CBc[R.ja_off + L.qoff] = Q.qc;
+    quad_store(CBc, R.o.y, L, anchor, Q.qc);
     if constexpr (JPOS) pc = anchor - quad_rotate(R.vj, Qn);
     else pc = pcb;
-    CBc[R.r2.x + L.poff] = pc;
-    CBc[R.r2.x + L.qoff] = Qn.qc;
+    quad_store(CBc, R.o.z, L, pc, Qn.qc);
     Q = Qn;
 }
 // a step that only starts bodies (no position has a joint in it)
@@ -664,21 +666,20 @@ template <int RW, bool PARENT>
 __device__ __forceinline__ void fk_step_quad_body(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, float &pc, QuadQuat &Q,
                                                   float *CBc, const FkQuadLane &L) {
     if constexpr (PARENT) {
-        const int po = R.par_off >= 0 ? R.par_off : R.r2.x;
-        const float pl = CBc[po + L.poff], ql = CBc[po + L.qoff];
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
-        pc = R.par_off >= 0 ? pl : pc;
-        quad_derive(Q, R.par_off >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
+        const int po = R.o.x >= 0 ? R.o.x : R.o.z;
+        const float pl = CBc[po + L.poff], ql = CBc[po + L.poff + kXq];
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
+        pc = R.o.x >= 0 ? pl : pc;
+        quad_derive(Q, R.o.x >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
     } else {
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
     }
     pc = pc + quad_rotate(R.vb, Q);
-    CBc[R.r2.x + L.poff] = pc;
-    CBc[R.r2.x + L.qoff] = Q.qc;
+    quad_store(CBc, R.o.z, L, pc, Q.qc);
 }
 template <int RW>
-__device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, const int code, float &pc,
-                                             QuadQuat &Q, float *CBc, const float *qe, const float *jrec, const FkQuadLane &L) {
+__device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N, const float *rec, const float *next_rec, const int code,
+                                             float &pc, QuadQuat &Q, float *CBc, const float *qe, const float *jrec, const FkQuadLane &L) {
     const int form = code >> 8;
     if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, true, true, false>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_JOINT) fk_step_quad_joint<RW, true, false, false>(R, N, next_rec, pc, Q, CBc, L);
@@ -688,10 +689,10 @@ __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N,
     else if (form == FK_FORM_PARENT_BODY_QJOINT) fk_step_quad_joint<RW, false, true, true>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_BODY) fk_step_quad_body<RW, false>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_PARENT_BODY) fk_step_quad_body<RW, true>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_IDLE) fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
+    else if (form == FK_FORM_IDLE) fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
     else {
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.r2.y, L);
-        fk_step_quad_general<RW>(R, code & 255, pc, Q, CBc, qe, jrec, L);
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
+        fk_step_quad_general<RW>(R, rec, code & 255, pc, Q, CBc, qe, jrec, L);
     }
     wave_sync();
 }
@@ -702,9 +703,9 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
     const int pp = lf >> 2, c = lf & 3;
     if (!(active && pp < W)) return;  // whole quads: the DPP operands below stay inside a quad
     FkQuadLane L;
+    L.c = c;
     L.voff = c ? c - 1 : 0;
-    L.poff = c ? c - 1 : kXq;
-    L.qoff = kXq + c;
+    L.poff = c ? c - 1 : 3;
     const int sgn = (int)0x80000000u;
     L.m1 = (c == 0 || c == 2) ? sgn : 0;
     L.m2 = (c == 0 || c == 3) ? sgn : 0;
@@ -724,10 +725,12 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
     for (int ml = 0; ml < n_ml; ml += 2) {
         const int fl = __builtin_amdgcn_readfirstlane(fl_v);
         fl_v = hdr[(ml >> 1) + 1];
+        const float *r0 = sp;
         sp += stride;
-        fk_step_quad<RW>(A, B, sp, fl & 0xFFFF, pc, Q, CBc, qe, jrec, L);
+        const float *r1 = sp;
+        fk_step_quad<RW>(A, B, r0, sp, fl & 0xFFFF, pc, Q, CBc, qe, jrec, L);
         if (ml + 2 < n_ml) sp += stride;
-        fk_step_quad<RW>(B, A, sp, (fl >> 16) & 0xFFFF, pc, Q, CBc, qe, jrec, L);
+        fk_step_quad<RW>(B, A, r1, sp, (fl >> 16) & 0xFFFF, pc, Q, CBc, qe, jrec, L);
     }
 }
 

@@ -13,7 +13,7 @@ constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 // A lane of a G-lane group takes the sites k = r * G + lane, r < kSiteRounds: their keypoints and loss terms stay in
 // registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
 constexpr int kSiteRounds = 3;
-// A transform entry in a chain's LDS region: position (3 words) then quaternion (4 words).  Used for the body
+// A transform entry in a chain's LDS region: position (3 words) then quaternion (4 words, in the order x, y, z, w).  Used for the body
 // transforms (c_bx), the per-joint {anchor, pre-joint quaternion} entries (c_ja; the pre-pass parks the joint-local
 // quaternion in the quaternion words) and, as {f, t}, for the site wrenches and range sums.  Packed (7 words) by
 // default; -DSTAC_XF_WORDS=8 pads the entries to 16 bytes so that they move with two ds_read_b128 / ds_write_b128
@@ -24,6 +24,8 @@ constexpr int kSiteRounds = 3;
 #endif
 constexpr int kXf = STAC_XF_WORDS;     // 8 (aligned, ds_*_b128) or 7 (packed: 12 % less LDS per chain, scalar LDS accesses)
 constexpr int kXq = kXf == 8 ? 4 : 3;  // word of the quaternion (second vector) inside an entry
+constexpr int kXw = kXq + 3;           // a quaternion is stored (x, y, z, w): lane c of a quad then finds its quaternion
+                                       // component kXq words behind its position component (stac_device.hpp, FkQuadLane)
 
 // Records are 16-byte aligned so the kernel fetches them with ds_read_b128.
 struct BodyRec {      // 12 words
@@ -69,16 +71,16 @@ struct RangeRec { int32_t lo, hi; };
 // common step has no divergent branch and no select.  All offsets are word offsets into the chain's LDS region.
 struct FkStep {       // 12 words (+4 when some active body has a non-identity body_quat)
     float bpos[3];    // body_pos, or zeros
-    float jpos[3];    // jnt_pos, or zeros
+    int32_t kind;     // FK_KIND_*
     int32_t par_off;  // transform of the parent (c_bx + kXf * index) when another lane produced it, else -1 (the
                       // lane's running transform is the parent's)
     int32_t ja_off;   // this joint's anchor / pre-joint quaternion entry (c_ja + kXf * j); no joint in this step: c_sink
     int32_t xf_off;   // where the body's transform goes after this step (c_bx + kXf * index); not stored: c_sink
     int32_t ql_next;  // joint-local quaternion of this position's NEXT step (fetched one step ahead), or the
                       // identity quaternion of the world entry (c_bx + kXq)
-    int32_t kind;     // FK_KIND_*
+    float jpos[3];    // jnt_pos, or zeros
     int32_t aux;      // free: qpos address; slide: active joint index
-    // float bquat[4] follows when PlanHeader::fk_rec_words == 16
+    // float bquat[4] (w, x, y, z) follows when PlanHeader::fk_rec_words == 16
 };
 enum : int32_t { FK_KIND_PLAIN = 0, FK_KIND_FREE = 1, FK_KIND_SLIDE = 2 };
 // per-micro-level flags (wave-uniform: every chain of a wavefront runs the same program in lockstep): SOME position ...
