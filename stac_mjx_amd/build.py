@@ -26,22 +26,41 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libstac_hip.so)")
 
 
+STAMP = CSRC / "libstac_hip.so.stamp"
+
+
+def source_digest() -> str:
+    """sha256 over the sources, headers and flags: what the library was built from (modification times do not survive a copy
+    of the tree to another machine)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in SOURCES + HEADERS:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not LIB.exists():
+    if not LIB.exists() or not STAMP.exists():
         return True
-    t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+    return STAMP.read_text().strip() != source_digest()
 
 
 def build_extension(force: bool = False, verbose: bool = False) -> Path:
     if not force and not is_stale():
         return LIB
+    import time
+
     cmd = [hipcc_path(), *FLAGS, *map(str, SOURCES), "-o", str(LIB)]
+    t0 = time.perf_counter()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    STAMP.write_text(source_digest() + "\n")
     if verbose:
         print(res.stdout + res.stderr)
+        print(f"[stac build] {' '.join(cmd)}\n[stac build] compiled in {time.perf_counter() - t0:.0f} s, sources sha256 {source_digest()[:16]}")
     return LIB
 
 
