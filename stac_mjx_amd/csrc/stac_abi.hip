@@ -154,7 +154,7 @@ extern "C" int32_t stac_device_count(void) {
 // The FK program of the bodies in `need` (null: all active bodies): a header (one FK_ML_* flag word per micro-level,
 // then per position the ql offset of its first step) and the FkStep records at (micro_level * max_width + position in
 // the level).  Positions are those of the full layout, so a child still follows its parent on one lane.
-static std::vector<int32_t> build_fk_program(const stac_model *m, const char *need, int *n_mlev_out) {
+static std::vector<int32_t> build_fk_program(const stac_model *m, const char *need, int *n_mlev_out, int *uniform_out = nullptr) {
     const PlanHeader &h = m->h;
     const int W = h.max_width, rw = h.fk_rec_words, nlev = h.nlev, hw = h.fk_hdr_words;
     const std::vector<int> &lev_adr = m->h_lev_adr;
@@ -207,10 +207,21 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
                     const float *jp = m->h_aj_pos.data() + 3 * j;
                     for (int c = 0; c < 3; ++c) r[8 + c] = f2i(jp[c]);
                     r[5] = h.c_ja + kXf * j;
-                    ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + kXq;
-                    prog[ml >> 1] |= FK_ML_JOINT << fsh;
-                    if (jp[0] != 0.0f || jp[1] != 0.0f || jp[2] != 0.0f) prog[ml >> 1] |= FK_ML_JPOS << fsh;
-                    if (ty == STAC_JNT_FREE) { r[3] = FK_KIND_FREE; r[11] = m->h_aj_qadr[j]; prog[ml >> 1] |= FK_ML_SPECIAL << fsh; }
+                    const bool free_as_parent = ty == STAC_JNT_FREE && i == 0 && br.parent == 0 && (br.flags & 1);
+                    if (!free_as_parent) {
+                        ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + kXq;
+                        prog[ml >> 1] |= FK_ML_JOINT << fsh;
+                        if (jp[0] != 0.0f || jp[1] != 0.0f || jp[2] != 0.0f) prog[ml >> 1] |= FK_ML_JPOS << fsh;
+                    }
+                    if (free_as_parent) {
+                        // A free joint on a top-level body without orientation is a plain step on a synthetic parent: the
+                        // pre-pass leaves {qpos[0:3], normalised quaternion} in the joint's own entry, and with body_pos = 0,
+                        // an identity joint quaternion and jnt_pos = 0 the step reproduces exactly that transform
+                        // (anchor = position; the free joint's gradient does not look at the pre-joint quaternion).
+                        r[4] = h.c_ja + kXf * j;
+                        prog[ml >> 1] |= FK_ML_PARENT_LDS << fsh;
+                        for (int c = 0; c < 3; ++c) { r[c] = 0; r[8 + c] = 0; }
+                    } else if (ty == STAC_JNT_FREE) { r[3] = FK_KIND_FREE; r[11] = m->h_aj_qadr[j]; prog[ml >> 1] |= FK_ML_SPECIAL << fsh; }
                     if (ty == STAC_JNT_SLIDE) { r[3] = FK_KIND_SLIDE; r[11] = j; prog[ml >> 1] |= (FK_ML_SPECIAL | FK_ML_JPOS) << fsh; }
                 }
                 if (i == nsteps - 1 && xfs >= 0) r[6] = h.c_bx + kXf * xfs;
@@ -219,22 +230,15 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     for (int ml = 0; ml + 1 < n_mlev; ++ml)
         for (int pp = 0; pp < W; ++pp) prog[hw + ((size_t)ml * W + pp) * rw + 7] = ql_of[(size_t)(ml + 1) * W + pp];
     for (int pp = 0; pp < W; ++pp) prog[(h.n_mlev_hdr >> 1) + pp] = ql_of[pp];  // first steps: fetched by the prologue
+    bool uniform = true;
     for (int ml = 0; ml < n_mlev; ++ml) {  // step form (FK_FORM_*) next to the flags
         const int fsh = 16 * (ml & 1), fl = (prog[ml >> 1] >> fsh) & 255;
+        // hinge / ball steps on neutral data where a part does not apply (body_pos = 0, jnt_pos = 0, identity joint
+        // quaternion: exact no-ops; a position without a joint stores to the sink); free and slide joints and oriented
+        // bodies take the general step
         int form = FK_FORM_GENERAL;
-        if ((fl & (FK_ML_JOINT | FK_ML_JPOS | FK_ML_SPECIAL | FK_ML_BQUAT)) == (FK_ML_JOINT | FK_ML_JPOS)) {
-            if (!(fl & FK_ML_PARENT_LDS)) form = (fl & FK_ML_BODY) ? FK_FORM_BODY_JOINT : FK_FORM_JOINT;
-            else if (fl & FK_ML_BODY) form = FK_FORM_PARENT_BODY_JOINT;
-        } else if (fl == 0) {
-            form = FK_FORM_IDLE;
-        } else if (fl == FK_ML_BODY) {
-            form = FK_FORM_BODY;
-        } else if (fl == (FK_ML_BODY | FK_ML_PARENT_LDS)) {
-            form = FK_FORM_PARENT_BODY;
-        } else if ((fl & (FK_ML_JOINT | FK_ML_JPOS | FK_ML_SPECIAL | FK_ML_BQUAT)) == FK_ML_JOINT) {
-            if (!(fl & FK_ML_PARENT_LDS)) form = (fl & FK_ML_BODY) ? FK_FORM_BODY_QJOINT : FK_FORM_QJOINT;
-            else if (fl & FK_ML_BODY) form = FK_FORM_PARENT_BODY_QJOINT;
-        }
+        if (!(fl & (FK_ML_SPECIAL | FK_ML_BQUAT))) form = (fl & FK_ML_PARENT_LDS) ? FK_FORM_PARENT_BODY_JOINT : FK_FORM_BODY_JOINT;
+        if (form == FK_FORM_GENERAL) uniform = false;
         prog[ml >> 1] |= form << (fsh + 8);
     }
     if (m->dbg.verbose) {
@@ -243,6 +247,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
         fprintf(stderr, "\n");
     }
     *n_mlev_out = n_mlev;
+    if (uniform_out) *uniform_out = uniform ? 1 : 0;
     return prog;
 }
 
@@ -513,7 +518,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
             h.fk_hdr_words = ((h.n_mlev_hdr >> 1) + h.max_width + 3) & ~3;  // one flag word per pair of micro-levels
         }
         int n_mlev = 0;
-        const std::vector<int32_t> prog = build_fk_program(m, nullptr, &n_mlev);
+        const std::vector<int32_t> prog = build_fk_program(m, nullptr, &n_mlev, &h.fk_uniform);  // (a pruned program is a subset)
         h.off_fkstep = put_raw(prog.data(), prog.size());
         h.n_mlev = n_mlev;
         std::vector<int32_t> blank(prog.size(), 0);

@@ -197,6 +197,7 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
             const Q4 qn = normalize4(ld4(qe + qa), &n);
             st4(qe + qa, qn);  // written back, like MJX
             st_tquat(ja + kXf * j, qn);
+            if (ty == JFREE) st_tpos(ja + kXf * j, ld3(qe + ad));  // {position, quaternion}: the FK program's synthetic parent of the body
             // the gradient pass needs |q| and the unit quaternion after qe's region has been reused: they are kept by
             // the joint's ordinal among the quaternion joints (JointRec::q0 of a free / ball joint)
             const int qord = __builtin_bit_cast(int, lds4(jr + 4).w);
@@ -561,12 +562,20 @@ struct FkQuadLane {
 };
 // {position component, quaternion component} of the lane into the entry at word offset `off`: one LDS instruction
 __device__ __forceinline__ void quad_store(float *CBc, const int off, const FkQuadLane &L, const float p, const float q) {
-    const unsigned adr = (unsigned)(size_t)(CBc + off + L.poff);
-    if constexpr (kXq == 3) asm volatile("ds_write2_b32 %0, %1, %2 offset1:3" ::"v"(adr), "v"(p), "v"(q) : "memory");
-    else asm volatile("ds_write2_b32 %0, %1, %2 offset1:4" ::"v"(adr), "v"(p), "v"(q) : "memory");
+#ifdef STAC_EXP_NOSTORE
+    return;
+#endif
+    // two plain stores, position component first: the compiler merges them into one ds_write2_b32 (data0 = the lower
+    // offset).  An asm statement here would make every wave_sync() drain the LDS queue (an opaque memory clobber).
+    float *e = CBc + off + L.poff;
+    e[0] = p;
+    e[kXq] = q;
 }
 template <int RW>
 __device__ __forceinline__ void fk_fetch_quad(FkQuadRegs &R, const float *rec, const float *CBc, const int ql_off, const FkQuadLane &L) {
+#ifdef STAC_EXP_NOFETCH
+    return;
+#endif
     R.vb = rec[L.voff];
     R.vj = rec[8 + L.voff];
     R.o = lds4i(rec + 4);
@@ -637,7 +646,12 @@ __device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRe
     }
     float pcb, ra;
     QuadQuat Qn;
+#ifdef STAC_EXP_NOARITH
+    Qn = Q; pcb = pc; ra = R.vj;
+    if constexpr (false) {
+#else
     if constexpr (JPOS) {
+#endif
         quad_joint_fused<BODY>(pc, Q, R.vb, R.vj, R.ql, pcb, ra, Qn);
     } else if constexpr (BODY) {
         quad_joint_fused<false>(pc, Q, R.vb, R.vb, R.ql, pcb, ra, Qn);  // the same block: rotate(bpos, q) beside q * ql
@@ -656,8 +670,12 @@ __device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRe
     }
     const float anchor = JPOS ? ra + pcb : pcb;
     quad_store(CBc, R.o.y, L, anchor, Q.qc);
+#ifdef STAC_EXP_NOARITH
+    pc = anchor;
+#else
     if constexpr (JPOS) pc = anchor - quad_rotate(R.vj, Qn);
     else pc = pcb;
+#endif
     quad_store(CBc, R.o.z, L, pc, Qn.qc);
     Q = Qn;
 }
@@ -675,12 +693,17 @@ __device__ __forceinline__ void fk_step_quad_body(const FkQuadRegs &R, FkQuadReg
         fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
     }
     pc = pc + quad_rotate(R.vb, Q);
+    quad_store(CBc, R.o.y, L, pc, Q.qc);  // (the sink: every form ends with the same two stores, see fk_step_quad)
     quad_store(CBc, R.o.z, L, pc, Q.qc);
 }
 template <int RW>
 __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N, const float *rec, const float *next_rec, const int code,
                                              float &pc, QuadQuat &Q, float *CBc, const float *qe, const float *jrec, const FkQuadLane &L) {
+    // Every form issues its LDS operations in the same pattern -- [parent loads] fetch of the next record, two stores --
+    // because the forms join again before the next step: s_waitcnt counts are merged over all predecessors, and one form
+    // with fewer operations behind its fetch would make EVERY step wait for the stores of the step before to complete.
     const int form = code >> 8;
+#ifdef STAC_FORMS_ALL  // (experiment: one straight-line form per flag combination)
     if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, true, true, false>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_JOINT) fk_step_quad_joint<RW, true, false, false>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<RW, true, true, true>(R, N, next_rec, pc, Q, CBc, L);
@@ -689,12 +712,27 @@ __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N,
     else if (form == FK_FORM_PARENT_BODY_QJOINT) fk_step_quad_joint<RW, false, true, true>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_BODY) fk_step_quad_body<RW, false>(R, N, next_rec, pc, Q, CBc, L);
     else if (form == FK_FORM_PARENT_BODY) fk_step_quad_body<RW, true>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_IDLE) fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
+    else if (form == FK_FORM_IDLE) {
+        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
+        quad_store(CBc, R.o.y, L, pc, Q.qc);  // (the sink, twice)
+        quad_store(CBc, R.o.z, L, pc, Q.qc);
+    } else {
+#else
+    // Two straight-line forms and the general one.  More forms -- one per flag combination, without the arithmetic a
+    // step does not need -- are each faster alone (a program of BODY steps only: 195 cycles per step, of QJOINT steps
+    // 208, against 385 / 486 for the two below), but every alternative is one more block of the structurised control
+    // flow that EVERY step walks through: ten forms cost the rodent's 14-step program 10.1 k cycles, against 5.9 k
+    // for the sum of its steps.  The arithmetic is not what a step costs: without it the program takes 3 % less.
+    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, true, true, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<RW, true, true, true>(R, N, next_rec, pc, Q, CBc, L);
     else {
+#endif
         fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
         fk_step_quad_general<RW>(R, rec, code & 255, pc, Q, CBc, qe, jrec, L);
     }
+#ifndef STAC_EXP_NOSYNC
     wave_sync();
+#endif
 }
 template <int RW>
 __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
@@ -719,9 +757,24 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
     quad_derive(Q, c == 0 ? 1.f : 0.f, L.m1, L.m2, L.m3);
     FkQuadRegs A, B;
     A.bq = B.bq = c == 0 ? 1.f : 0.f;
-    fk_fetch_quad<RW>(A, sp, CBc, hdr[(H.n_mlev_hdr >> 1) + pp], L);
-    const int stride = RW * W;
     int fl_v = hdr[0];
+    fk_fetch_quad<RW>(A, sp, CBc, hdr[(H.n_mlev_hdr >> 1) + pp], L);
+    quad_store(CBc, H.c_sink, L, pc, Q.qc);  // (the pattern of a step: see fk_step_quad)
+    quad_store(CBc, H.c_sink, L, pc, Q.qc);
+    const int stride = RW * W;
+    if (H.fk_uniform) {
+        // every step is the same straight-line code (parents by select, body / joint parts on neutral data): no flags, no
+        // dispatch, nothing for s_waitcnt to be conservative about
+        for (int ml = 0; ml < n_ml; ml += 2) {
+            sp += stride;
+            fk_step_quad_joint<RW, true, true, true>(A, B, sp, pc, Q, CBc, L);
+            wave_sync();
+            if (ml + 2 < n_ml) sp += stride;
+            fk_step_quad_joint<RW, true, true, true>(B, A, sp, pc, Q, CBc, L);
+            wave_sync();
+        }
+        return;
+    }
     for (int ml = 0; ml < n_ml; ml += 2) {
         const int fl = __builtin_amdgcn_readfirstlane(fl_v);
         fl_v = hdr[(ml >> 1) + 1];

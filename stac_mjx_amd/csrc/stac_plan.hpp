@@ -161,6 +161,8 @@ struct PlanHeader {
                            // first-step ql offsets
     int32_t n_mlev;        // micro-levels of the FK program
     int32_t fk_rec_words;  // 12, or 16 when the records carry body_quat
+    int32_t fk_uniform;    // 1: no step of the program needs the general form (no slide joint, no oriented body, free joints
+                           // only on top-level bodies): the kernel runs ONE straight-line step without any dispatch
 };
 
 // Full-model tables for the stand-alone FK / offset-phase kernels (device pointers).
