@@ -359,6 +359,33 @@ __device__ __forceinline__ void fk_step(const FkRegs &R, FkRegs &N, const float 
     }
     wave_sync();
 }
+// The step of a uniform program (PlanHeader::fk_uniform), one lane per position: the same straight-line arithmetic for
+// every position and step, on neutral data where a part does not apply; the only branch is wave-uniform (`par`: some
+// position of this step loads its parent).  Bit-identical to fk_step.
+template <int RW>
+__device__ __forceinline__ void fk_step_uniform(const FkRegs &R, FkRegs &N, const float *next_rec, const bool par, V3 &pos, Q4 &quat,
+                                                float *CBc) {
+    if (par) {
+        const int src = R.r1.x >= 0 ? R.r1.x : R.r1.z;  // (any valid entry: the loaded values are dropped)
+        const V3 lp = ld_tpos(CBc + src);
+        const Q4 lq = ld_tquat(CBc + src);
+        fk_fetch<RW>(N, next_rec, CBc, R.r1.w);
+        if (R.r1.x >= 0) { pos = lp; quat = lq; }
+    } else {
+        fk_fetch<RW>(N, next_rec, CBc, R.r1.w);
+    }
+    pos = add3(pos, rotate(V3{R.r0.x, R.r0.y, R.r0.z}, quat));
+    const V3 jp = {R.r2.x, R.r2.y, R.r2.z};
+    const Q4 prequat = quat;
+    const V3 anchor = add3(rotate(jp, quat), pos);
+    quat = qmul(quat, R.ql);
+    pos = sub3(anchor, rotate(jp, quat));
+    st_tpos(CBc + R.r1.y, anchor);
+    st_tquat(CBc + R.r1.y, prequat);
+    st_tpos(CBc + R.r1.z, pos);
+    st_tquat(CBc + R.r1.z, quat);
+    wave_sync();
+}
 template <int RW>
 __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
                                            const bool active, const bool store_ja, const int prog_off, const int n_ml) {
@@ -377,6 +404,18 @@ __device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, 
     fk_fetch<RW>(A, sp, CBc, hdr[(H.n_mlev_hdr >> 1) + (on ? lf : 0)]);
     const int stride = RW * W;
     int fl_v = hdr[0];
+    if (H.fk_uniform) {
+        if (!on) return;  // (wave_sync needs no company: LDS operations of a wave execute in order)
+        for (int ml = 0; ml < n_ml; ml += 2) {
+            const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+            fl_v = hdr[(ml >> 1) + 1];
+            sp += stride;
+            fk_step_uniform<RW>(A, B, sp, (fl & FK_ML_PARENT_LDS) != 0, pos, quat, CBc);
+            if (ml + 2 < n_ml) sp += stride;
+            fk_step_uniform<RW>(B, A, sp, ((fl >> 16) & FK_ML_PARENT_LDS) != 0, pos, quat, CBc);
+        }
+        return;
+    }
     // two steps per trip so that the fetched record never has to be copied (n_mlev is even: padded by the host)
     for (int ml = 0; ml < n_ml; ml += 2) {
         const int fl = __builtin_amdgcn_readfirstlane(fl_v);
