@@ -540,9 +540,9 @@ static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
 constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr int kCus = 256;
 // latency mode: up to this many chains a chain is spread over 8 / 4 wavefronts of a workgroup (else one per chain)
-// (measured, rodent, 250-frame clips, profiles/r02/lat_sweep.txt: with the four-lanes-per-position kinematics four and
-// eight wavefronts per chain are within 1 % of each other from 40 to 256 chains, four slightly ahead, and four hold
-// twice as many chains: eight are kept behind STAC_HIP_SPECG=64)
+// (measured, rodent, 250-frame clips, profiles/r02/lat_sweep.txt: with the four-lanes-per-position kinematics four
+// wavefronts per chain are 6-12 % ahead of eight from 40 to 256 chains and hold twice as many chains: eight are kept
+// behind STAC_HIP_SPECG=64)
 constexpr long kSpec64MaxChains = 0, kSpec32MaxChains = 512;
 // latency mode with 4 roles per chain from this many chains on (never auto-selected below: developer switch STAC_HIP_SPECR)
 constexpr long kSpec4MinChains = 1L << 40;
