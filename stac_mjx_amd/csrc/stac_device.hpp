@@ -505,83 +505,49 @@ __device__ __forceinline__ float quad_qmul(const QuadQuat &Q, const float vq) {
 // one every 4; the compiler schedules an asm block as a unit).  Same operations, same operands, same order per
 // result as quad_rotate / quad_qmul / quad_derive.  On return: pcb = pc + rotate(bpos, q) (BODY) or pc;
 // ra = rotate(jpos, q); Qn = everything of the new quaternion except S2 and the signed copies.
-template <bool BODY>
 __device__ __forceinline__ void quad_joint_fused(const float pc, const QuadQuat &Q, const float vb, const float vj, const float ql,
                                                  float &pcb, float &ra, QuadQuat &Qn) {
     float r, nS, nUX, nUY, nUZ, nU1, nU2, nK, tB, tA, mB;
-    if constexpr (BODY) {
-        asm("s_nop 0\n\t"
-            "v_mul_f32 %0, %13, %27\n\t"                          // M  r = s ql_c
-            "v_mul_f32_dpp %8, %25, %14" STAC_DPP("1,1,1,1")      // B  uv = bpos.x u.x
-            "v_mul_f32_dpp %9, %26, %14" STAC_DPP("1,1,1,1")      // A  uv = jpos.x u.x
-            "v_fmac_f32_dpp %0, %27, %22" STAC_DPP("1,0,3,2")     // M
-            "v_mul_f32_dpp %10, %25, -%18" STAC_DPP("0,2,3,1")    // B  m = -(u_(c+2) bpos_(c+1))
-            "v_mul_f32_dpp %11, %26, -%18" STAC_DPP("0,2,3,1")    // A
-            "v_fmac_f32_dpp %0, %27, %23" STAC_DPP("2,3,0,1")     // M
-            "v_fmac_f32_dpp %8, %25, %15" STAC_DPP("2,2,2,2")     // B
-            "v_fmac_f32_dpp %9, %26, %15" STAC_DPP("2,2,2,2")     // A
-            "v_fmac_f32_dpp %0, %27, %24" STAC_DPP("3,2,1,0")     // M  r = component c of q * ql
-            "v_fmac_f32_dpp %10, %25, %17" STAC_DPP("0,3,1,2")    // B
-            "v_fmac_f32_dpp %11, %26, %17" STAC_DPP("0,3,1,2")    // A
-            "v_fmac_f32_dpp %8, %25, %16" STAC_DPP("3,3,3,3")     // B
-            "v_fmac_f32_dpp %9, %26, %16" STAC_DPP("3,3,3,3")     // A
-            "v_mov_b32_dpp %1, %0" STAC_DPP("0,0,0,0")            // M  broadcasts of the product
-            "v_mov_b32_dpp %2, %0" STAC_DPP("1,1,1,1")
-            "v_mov_b32_dpp %3, %0" STAC_DPP("2,2,2,2")
-            "v_mov_b32_dpp %4, %0" STAC_DPP("3,3,3,3")
-            "v_add_f32 %8, %8, %8\n\t"                            // B  t = 2 u.v
-            "v_add_f32 %9, %9, %9\n\t"                            // A
-            "v_mul_f32 %7, %2, %2\n\t"                            // M  u.u
-            "v_mul_f32 %8, %8, %12\n\t"                           // B  t u_c
-            "v_mul_f32 %9, %9, %12\n\t"                           // A
-            "v_fmac_f32 %7, %3, %3\n\t"                           // M
-            "v_fmac_f32 %8, %19, %25\n\t"                         // B  + k v_c
-            "v_fmac_f32 %9, %19, %26\n\t"                         // A
-            "v_fmac_f32 %7, %4, %4\n\t"                           // M
-            "v_fmac_f32 %8, %20, %10\n\t"                         // B  + s2 (u x v)_c
-            "v_fmac_f32 %9, %20, %11\n\t"                         // A
-            "v_fma_f32 %7, %1, %1, -%7\n\t"                       // M  k = s^2 - u.u
-            "v_mov_b32_dpp %5, %0" STAC_DPP("0,2,3,1")            // M  u_(c+1)
-            "v_mov_b32_dpp %6, %0" STAC_DPP("0,3,1,2")            // M  u_(c+2)
-            "v_add_f32 %10, %21, %8"                              // B  pcb = pc + rotate(bpos, q)
-            : "=&v"(r), "=&v"(nS), "=&v"(nUX), "=&v"(nUY), "=&v"(nUZ), "=&v"(nU1), "=&v"(nU2), "=&v"(nK), "=&v"(tB), "=&v"(tA),
-              "=&v"(mB), "=&v"(ra)
-            : "v"(Q.qc), "v"(Q.S), "v"(Q.UX), "v"(Q.UY), "v"(Q.UZ), "v"(Q.U1), "v"(Q.U2), "v"(Q.K), "v"(Q.S2), "v"(pc), "v"(Q.SX),
-              "v"(Q.SY), "v"(Q.SZ), "v"(vb), "v"(vj), "v"(ql));
-        pcb = mB;
-        ra = tA;  // (the block kept the anchor chain's cross term in `ra`)
-    } else {
-        asm("s_nop 0\n\t"
-            "v_mul_f32 %0, %11, %23\n\t"                          // M  r = s ql_c
-            "v_mul_f32_dpp %8, %22, %12" STAC_DPP("1,1,1,1")      // A  uv = jpos.x u.x
-            "v_mul_f32_dpp %9, %22, -%16" STAC_DPP("0,2,3,1")     // A  m
-            "v_fmac_f32_dpp %0, %23, %19" STAC_DPP("1,0,3,2")     // M
-            "v_fmac_f32_dpp %8, %22, %13" STAC_DPP("2,2,2,2")     // A
-            "v_fmac_f32_dpp %9, %22, %15" STAC_DPP("0,3,1,2")     // A
-            "v_fmac_f32_dpp %0, %23, %20" STAC_DPP("2,3,0,1")     // M
-            "v_fmac_f32_dpp %8, %22, %14" STAC_DPP("3,3,3,3")     // A
-            "v_fmac_f32_dpp %0, %23, %21" STAC_DPP("3,2,1,0")     // M  r = component c of q * ql
-            "v_add_f32 %8, %8, %8\n\t"                            // A  t
-            "s_nop 0\n\t"
-            "v_mov_b32_dpp %1, %0" STAC_DPP("0,0,0,0")            // M
-            "v_mov_b32_dpp %2, %0" STAC_DPP("1,1,1,1")
-            "v_mul_f32 %8, %8, %10\n\t"                           // A  t u_c
-            "v_mov_b32_dpp %3, %0" STAC_DPP("2,2,2,2")
-            "v_mov_b32_dpp %4, %0" STAC_DPP("3,3,3,3")
-            "v_fmac_f32 %8, %17, %22\n\t"                         // A  + k v_c
-            "v_mul_f32 %7, %2, %2\n\t"                            // M  u.u
-            "v_mov_b32_dpp %5, %0" STAC_DPP("0,2,3,1")
-            "v_fmac_f32 %7, %3, %3\n\t"
-            "v_fmac_f32 %8, %18, %9\n\t"                          // A  + s2 (u x v)_c
-            "v_fmac_f32 %7, %4, %4\n\t"
-            "v_mov_b32_dpp %6, %0" STAC_DPP("0,3,1,2")
-            "v_fma_f32 %7, %1, %1, -%7"                           // M  k
-            : "=&v"(r), "=&v"(nS), "=&v"(nUX), "=&v"(nUY), "=&v"(nUZ), "=&v"(nU1), "=&v"(nU2), "=&v"(nK), "=&v"(tA), "=&v"(mB)
-            : "v"(Q.qc), "v"(Q.S), "v"(Q.UX), "v"(Q.UY), "v"(Q.UZ), "v"(Q.U1), "v"(Q.U2), "v"(Q.K), "v"(Q.S2), "v"(Q.SX),
-              "v"(Q.SY), "v"(Q.SZ), "v"(vj), "v"(ql));
-        pcb = pc;
-        ra = tA;
-    }
+    asm("s_nop 0\n\t"
+        "v_mul_f32 %0, %13, %27\n\t"                          // M  r = s ql_c
+        "v_mul_f32_dpp %8, %25, %14" STAC_DPP("1,1,1,1")      // B  uv = bpos.x u.x
+        "v_mul_f32_dpp %9, %26, %14" STAC_DPP("1,1,1,1")      // A  uv = jpos.x u.x
+        "v_fmac_f32_dpp %0, %27, %22" STAC_DPP("1,0,3,2")     // M
+        "v_mul_f32_dpp %10, %25, -%18" STAC_DPP("0,2,3,1")    // B  m = -(u_(c+2) bpos_(c+1))
+        "v_mul_f32_dpp %11, %26, -%18" STAC_DPP("0,2,3,1")    // A
+        "v_fmac_f32_dpp %0, %27, %23" STAC_DPP("2,3,0,1")     // M
+        "v_fmac_f32_dpp %8, %25, %15" STAC_DPP("2,2,2,2")     // B
+        "v_fmac_f32_dpp %9, %26, %15" STAC_DPP("2,2,2,2")     // A
+        "v_fmac_f32_dpp %0, %27, %24" STAC_DPP("3,2,1,0")     // M  r = component c of q * ql
+        "v_fmac_f32_dpp %10, %25, %17" STAC_DPP("0,3,1,2")    // B
+        "v_fmac_f32_dpp %11, %26, %17" STAC_DPP("0,3,1,2")    // A
+        "v_fmac_f32_dpp %8, %25, %16" STAC_DPP("3,3,3,3")     // B
+        "v_fmac_f32_dpp %9, %26, %16" STAC_DPP("3,3,3,3")     // A
+        "v_mov_b32_dpp %1, %0" STAC_DPP("0,0,0,0")            // M  broadcasts of the product
+        "v_mov_b32_dpp %2, %0" STAC_DPP("1,1,1,1")
+        "v_mov_b32_dpp %3, %0" STAC_DPP("2,2,2,2")
+        "v_mov_b32_dpp %4, %0" STAC_DPP("3,3,3,3")
+        "v_add_f32 %8, %8, %8\n\t"                            // B  t = 2 u.v
+        "v_add_f32 %9, %9, %9\n\t"                            // A
+        "v_mul_f32 %7, %2, %2\n\t"                            // M  u.u
+        "v_mul_f32 %8, %8, %12\n\t"                           // B  t u_c
+        "v_mul_f32 %9, %9, %12\n\t"                           // A
+        "v_fmac_f32 %7, %3, %3\n\t"                           // M
+        "v_fmac_f32 %8, %19, %25\n\t"                         // B  + k v_c
+        "v_fmac_f32 %9, %19, %26\n\t"                         // A
+        "v_fmac_f32 %7, %4, %4\n\t"                           // M
+        "v_fmac_f32 %8, %20, %10\n\t"                         // B  + s2 (u x v)_c
+        "v_fmac_f32 %9, %20, %11\n\t"                         // A
+        "v_fma_f32 %7, %1, %1, -%7\n\t"                       // M  k = s^2 - u.u
+        "v_mov_b32_dpp %5, %0" STAC_DPP("0,2,3,1")            // M  u_(c+1)
+        "v_mov_b32_dpp %6, %0" STAC_DPP("0,3,1,2")            // M  u_(c+2)
+        "v_add_f32 %10, %21, %8"                              // B  pcb = pc + rotate(bpos, q)
+        : "=&v"(r), "=&v"(nS), "=&v"(nUX), "=&v"(nUY), "=&v"(nUZ), "=&v"(nU1), "=&v"(nU2), "=&v"(nK), "=&v"(tB), "=&v"(tA),
+          "=&v"(mB), "=&v"(ra)
+        : "v"(Q.qc), "v"(Q.S), "v"(Q.UX), "v"(Q.UY), "v"(Q.UZ), "v"(Q.U1), "v"(Q.U2), "v"(Q.K), "v"(Q.S2), "v"(pc), "v"(Q.SX),
+          "v"(Q.SY), "v"(Q.SZ), "v"(vb), "v"(vj), "v"(ql));
+    pcb = mB;
+    ra = tA;  // (the block kept the anchor chain's cross term in `ra`)
     Qn.qc = r; Qn.S = nS; Qn.UX = nUX; Qn.UY = nUY; Qn.UZ = nUZ; Qn.U1 = nU1; Qn.U2 = nU2; Qn.K = nK;
 }
 struct FkQuadRegs {
@@ -601,9 +567,6 @@ struct FkQuadLane {
 };
 // {position component, quaternion component} of the lane into the entry at word offset `off`: one LDS instruction
 __device__ __forceinline__ void quad_store(float *CBc, const int off, const FkQuadLane &L, const float p, const float q) {
-#ifdef STAC_EXP_NOSTORE
-    return;
-#endif
     // two plain stores, position component first: the compiler merges them into one ds_write2_b32 (data0 = the lower
     // offset).  An asm statement here would make every wave_sync() drain the LDS queue (an opaque memory clobber).
     float *e = CBc + off + L.poff;
@@ -612,9 +575,6 @@ __device__ __forceinline__ void quad_store(float *CBc, const int off, const FkQu
 }
 template <int RW>
 __device__ __forceinline__ void fk_fetch_quad(FkQuadRegs &R, const float *rec, const float *CBc, const int ql_off, const FkQuadLane &L) {
-#ifdef STAC_EXP_NOFETCH
-    return;
-#endif
     R.vb = rec[L.voff];
     R.vj = rec[8 + L.voff];
     R.o = lds4i(rec + 4);
@@ -668,10 +628,10 @@ __device__ __forceinline__ void fk_step_quad_general(const FkQuadRegs &R, const 
     quad_store(CBc, R.o.y, L, anchor, prequat);
     quad_store(CBc, R.o.z, L, pc, Q.qc);
 }
-// The frequent forms (FK_FORM_*), straight-line.  JPOS: hinge / ball joints with an offset (jnt_pos != 0) -- else the
-// anchor is the body position and the position stays (exact).  BODY: the step starts bodies.  PARENT: some of them load
-// their parent's transform (issued ahead of the next record's fetch: the loads return in order).
-template <int RW, bool JPOS, bool BODY, bool PARENT>
+// The plain step, straight-line: hinge / ball joints on every position, on neutral data where a part does not apply
+// (body_pos = 0: the step does not start a body; jnt_pos = 0 and an identity joint quaternion: no joint).  PARENT: some
+// positions load their parent's transform (issued ahead of the next record's fetch: the loads return in order).
+template <int RW, bool PARENT>
 __device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, float &pc, QuadQuat &Q,
                                                    float *CBc, const FkQuadLane &L) {
     if constexpr (PARENT) {
@@ -685,55 +645,16 @@ __device__ __forceinline__ void fk_step_quad_joint(const FkQuadRegs &R, FkQuadRe
     }
     float pcb, ra;
     QuadQuat Qn;
-#ifdef STAC_EXP_NOARITH
-    Qn = Q; pcb = pc; ra = R.vj;
-    if constexpr (false) {
-#else
-    if constexpr (JPOS) {
-#endif
-        quad_joint_fused<BODY>(pc, Q, R.vb, R.vj, R.ql, pcb, ra, Qn);
-    } else if constexpr (BODY) {
-        quad_joint_fused<false>(pc, Q, R.vb, R.vb, R.ql, pcb, ra, Qn);  // the same block: rotate(bpos, q) beside q * ql
-        pcb = pc + ra;
-    } else {
-        Qn.qc = quad_qmul(Q, R.ql);
-    }
-    if constexpr (JPOS || BODY) {
-        Qn.S2 = Qn.S + Qn.S;
-        Qn.SX = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UX) ^ L.m1);
-        Qn.SY = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UY) ^ L.m2);
-        Qn.SZ = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UZ) ^ L.m3);
-    } else {
-        pcb = pc;
-        quad_derive(Qn, Qn.qc, L.m1, L.m2, L.m3);
-    }
-    const float anchor = JPOS ? ra + pcb : pcb;
+    quad_joint_fused(pc, Q, R.vb, R.vj, R.ql, pcb, ra, Qn);
+    Qn.S2 = Qn.S + Qn.S;
+    Qn.SX = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UX) ^ L.m1);
+    Qn.SY = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UY) ^ L.m2);
+    Qn.SZ = __builtin_bit_cast(float, __builtin_bit_cast(int, Qn.UZ) ^ L.m3);
+    const float anchor = ra + pcb;
     quad_store(CBc, R.o.y, L, anchor, Q.qc);
-#ifdef STAC_EXP_NOARITH
-    pc = anchor;
-#else
-    if constexpr (JPOS) pc = anchor - quad_rotate(R.vj, Qn);
-    else pc = pcb;
-#endif
+    pc = anchor - quad_rotate(R.vj, Qn);
     quad_store(CBc, R.o.z, L, pc, Qn.qc);
     Q = Qn;
-}
-// a step that only starts bodies (no position has a joint in it)
-template <int RW, bool PARENT>
-__device__ __forceinline__ void fk_step_quad_body(const FkQuadRegs &R, FkQuadRegs &N, const float *next_rec, float &pc, QuadQuat &Q,
-                                                  float *CBc, const FkQuadLane &L) {
-    if constexpr (PARENT) {
-        const int po = R.o.x >= 0 ? R.o.x : R.o.z;
-        const float pl = CBc[po + L.poff], ql = CBc[po + L.poff + kXq];
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
-        pc = R.o.x >= 0 ? pl : pc;
-        quad_derive(Q, R.o.x >= 0 ? ql : Q.qc, L.m1, L.m2, L.m3);
-    } else {
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
-    }
-    pc = pc + quad_rotate(R.vb, Q);
-    quad_store(CBc, R.o.y, L, pc, Q.qc);  // (the sink: every form ends with the same two stores, see fk_step_quad)
-    quad_store(CBc, R.o.z, L, pc, Q.qc);
 }
 template <int RW>
 __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N, const float *rec, const float *next_rec, const int code,
@@ -742,36 +663,18 @@ __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N,
     // because the forms join again before the next step: s_waitcnt counts are merged over all predecessors, and one form
     // with fewer operations behind its fetch would make EVERY step wait for the stores of the step before to complete.
     const int form = code >> 8;
-#ifdef STAC_FORMS_ALL  // (experiment: one straight-line form per flag combination)
-    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, true, true, false>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_JOINT) fk_step_quad_joint<RW, true, false, false>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<RW, true, true, true>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_BODY_QJOINT) fk_step_quad_joint<RW, false, true, false>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_QJOINT) fk_step_quad_joint<RW, false, false, false>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_PARENT_BODY_QJOINT) fk_step_quad_joint<RW, false, true, true>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_BODY) fk_step_quad_body<RW, false>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_PARENT_BODY) fk_step_quad_body<RW, true>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_IDLE) {
-        fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
-        quad_store(CBc, R.o.y, L, pc, Q.qc);  // (the sink, twice)
-        quad_store(CBc, R.o.z, L, pc, Q.qc);
-    } else {
-#else
     // Two straight-line forms and the general one.  More forms -- one per flag combination, without the arithmetic a
     // step does not need -- are each faster alone (a program of BODY steps only: 195 cycles per step, of QJOINT steps
     // 208, against 385 / 486 for the two below), but every alternative is one more block of the structurised control
     // flow that EVERY step walks through: ten forms cost the rodent's 14-step program 10.1 k cycles, against 5.9 k
     // for the sum of its steps.  The arithmetic is not what a step costs: without it the program takes 3 % less.
-    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, true, true, false>(R, N, next_rec, pc, Q, CBc, L);
-    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<RW, true, true, true>(R, N, next_rec, pc, Q, CBc, L);
+    if (form == FK_FORM_BODY_JOINT) fk_step_quad_joint<RW, false>(R, N, next_rec, pc, Q, CBc, L);
+    else if (form == FK_FORM_PARENT_BODY_JOINT) fk_step_quad_joint<RW, true>(R, N, next_rec, pc, Q, CBc, L);
     else {
-#endif
         fk_fetch_quad<RW>(N, next_rec, CBc, R.o.w, L);
         fk_step_quad_general<RW>(R, rec, code & 255, pc, Q, CBc, qe, jrec, L);
     }
-#ifndef STAC_EXP_NOSYNC
     wave_sync();
-#endif
 }
 template <int RW>
 __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
@@ -806,10 +709,10 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
         // dispatch, nothing for s_waitcnt to be conservative about
         for (int ml = 0; ml < n_ml; ml += 2) {
             sp += stride;
-            fk_step_quad_joint<RW, true, true, true>(A, B, sp, pc, Q, CBc, L);
+            fk_step_quad_joint<RW, true>(A, B, sp, pc, Q, CBc, L);
             wave_sync();
             if (ml + 2 < n_ml) sp += stride;
-            fk_step_quad_joint<RW, true, true, true>(B, A, sp, pc, Q, CBc, L);
+            fk_step_quad_joint<RW, true>(B, A, sp, pc, Q, CBc, L);
             wave_sync();
         }
         return;
@@ -842,10 +745,6 @@ __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, fl
                 else fk_program_quad<12>(H, P, CBc, lf, gf, active, prog_off, n_ml);
                 return;
             }
-#ifdef STAC_QUAD_ONLY
-            fk_levels(H, P, CBc, lf, gf, active, store_ja);
-            return;
-#endif
         }
         if (H.fk_rec_words == 16) fk_program<16>(H, P, CBc, lf, gf, active, store_ja, prog_off, n_ml);
         else fk_program<12>(H, P, CBc, lf, gf, active, store_ja, prog_off, n_ml);

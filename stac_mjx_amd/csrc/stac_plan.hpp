@@ -93,19 +93,14 @@ enum : int32_t {
     FK_ML_BQUAT = 32,      // ... starts a body with a non-identity body_quat
 };
 
-// The form of a micro-level's step, next to its flags (flags | form << 8, 16 bits per micro-level): the frequent flag
-// combinations run as straight-line code.
+// The form of a micro-level's step, next to its flags (flags | form << 8, 16 bits per micro-level), for programs that are
+// not uniform (PlanHeader::fk_uniform): the plain hinge / ball step on neutral data, with or without parents from LDS,
+// or the general step (free joints below the top level, slide joints, oriented bodies).  More forms -- one per flag
+// combination -- were each faster alone and slower together.
 enum : int32_t {
     FK_FORM_GENERAL = 0,            // by the flags
-    FK_FORM_BODY_JOINT = 1,         // BODY | JOINT | JPOS: every position composes with a parent it holds and applies a joint
-    FK_FORM_JOINT = 2,              // JOINT | JPOS: further joints of the bodies
+    FK_FORM_BODY_JOINT = 1,         // every position composes with a parent it holds and applies a joint
     FK_FORM_PARENT_BODY_JOINT = 3,  // as BODY_JOINT, some parents come from LDS
-    FK_FORM_BODY_QJOINT = 4,        // BODY | JOINT with jnt_pos = 0 everywhere (anchor = position, which stays)
-    FK_FORM_QJOINT = 5,             // JOINT alone, jnt_pos = 0
-    FK_FORM_PARENT_BODY_QJOINT = 6,
-    FK_FORM_IDLE = 7,               // nothing (padding step)
-    FK_FORM_BODY = 8,               // BODY alone: bodies without a joint
-    FK_FORM_PARENT_BODY = 9,
 };
 
 struct SiteRec {      // 4 words
