@@ -676,7 +676,7 @@ __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N,
     }
     wave_sync();
 }
-template <int RW>
+template <int RW, bool PSEL>
 __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
                                                 const bool active, const int prog_off, const int n_ml) {
     const int W = H.max_width;
@@ -708,11 +708,18 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
         // every step is the same straight-line code (parents by select, body / joint parts on neutral data): no flags, no
         // dispatch, nothing for s_waitcnt to be conservative about
         for (int ml = 0; ml < n_ml; ml += 2) {
+            const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+            fl_v = hdr[(ml >> 1) + 1];
             sp += stride;
-            fk_step_quad_joint<RW, true>(A, B, sp, pc, Q, CBc, L);
+            // PSEL: the parent part only in the steps that have one, behind one wave-uniform branch (measured: +1.5 % where
+            // several chains share the wavefront's instruction stream, -2.7 % in latency mode, where the step without any
+            // branch wins)
+            if (!PSEL || (fl & FK_ML_PARENT_LDS)) fk_step_quad_joint<RW, true>(A, B, sp, pc, Q, CBc, L);
+            else fk_step_quad_joint<RW, false>(A, B, sp, pc, Q, CBc, L);
             wave_sync();
             if (ml + 2 < n_ml) sp += stride;
-            fk_step_quad_joint<RW, true>(B, A, sp, pc, Q, CBc, L);
+            if (!PSEL || ((fl >> 16) & FK_ML_PARENT_LDS)) fk_step_quad_joint<RW, true>(B, A, sp, pc, Q, CBc, L);
+            else fk_step_quad_joint<RW, false>(B, A, sp, pc, Q, CBc, L);
             wave_sync();
         }
         return;
@@ -732,7 +739,7 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
 // FK of one chain by gf lanes: the program when every level fits the lanes (four lanes per position when QUAD and
 // they fit four times over), else the level loop.
 // n_ml_root > 0 (wave-uniform): every chain of the wavefront is in a root pass -- run the pruned program at off_fkroot.
-template <bool QUAD>
+template <bool QUAD, bool PSEL = false>
 __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
                                          const bool active, const bool store_ja, const bool use_levels,
                                          const int n_ml_root = 0) {
@@ -741,8 +748,8 @@ __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, fl
         const int n_ml = n_ml_root > 0 ? n_ml_root : H.n_mlev;
         if constexpr (QUAD) {
             if (4 * H.max_width <= gf) {
-                if (H.fk_rec_words == 16) fk_program_quad<16>(H, P, CBc, lf, gf, active, prog_off, n_ml);
-                else fk_program_quad<12>(H, P, CBc, lf, gf, active, prog_off, n_ml);
+                if (H.fk_rec_words == 16) fk_program_quad<16, PSEL>(H, P, CBc, lf, gf, active, prog_off, n_ml);
+                else fk_program_quad<12, PSEL>(H, P, CBc, lf, gf, active, prog_off, n_ml);
                 return;
             }
         }

@@ -301,7 +301,7 @@ void q_phase_kernel(const QArgs a) {
         // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)
         const bool root_pass = !a.single && kind < 2;
         const int n_ml_root = (a.n_mlev_root > 0 && !__any(st_in != ST_DONE && !root_pass)) ? a.n_mlev_root : 0;
-        fk_chain<(G >= 16)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root);
+        fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root);
 
         PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
