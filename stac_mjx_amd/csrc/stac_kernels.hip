@@ -216,9 +216,24 @@ void q_phase_kernel(const QArgs a) {
 
     PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
+    const int lg_outer = lg;
+    const int cb_words = (int)(CB - lds);
     while (__any(st != ST_DONE)) {
         PROF_TICK(0);  // loop control
         PROF_TRIP;
+        // Opaque per trip (168-VGPR build): every address that depends on the lane or on the chain's region is recomputed
+        // inside the trip (one VALU add each) instead of being hoisted out of the loop, where four dozen of them lived for
+        // the whole launch and were spilled: 192 -> 16 B of scratch per lane, 52 -> 12 MB of HBM traffic per 10 000-frame
+        // step, at 1.8 % of the frame rate (the reloads overlapped better than the adds do).  The 128-VGPR build spills
+        // either way and keeps the hoisted form.
+        int lg_t = lg_outer, cb_t = cb_words;
+        if constexpr (SPEC == 0 && WPE == 3) asm volatile("" : "+v"(lg_t), "+v"(cb_t));
+        const int lg = lg_t;
+        float *const CB = lds + cb_t;
+        float *const bx = CB + H.c_bx, *const ja = CB + H.c_ja, *const jn = CB + H.c_jn, *const qsv = CB + H.c_qsv;
+        float *const sw = CB + H.c_sw, *const gg = CB + H.c_gg, *const r2 = CB + H.c_r2;
+        float *const qe = CB + H.c_qe, *const kpl = CB + H.c_kp;
+        (void)jn; (void)qsv; (void)ja;
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
