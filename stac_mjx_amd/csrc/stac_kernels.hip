@@ -212,6 +212,12 @@ void q_phase_kernel(const QArgs a) {
             if (e < nq) { x[r] = hs[e]; y[r] = hs[nqpad + e]; q0[r] = hs[2 * nqpad + e]; }
         }
     }
+    if constexpr (SPEC != 0 && NW > 1) {
+        // the exchanged gradient vectors are zeroed ONCE: every pass rewrites the entries of all active joints, and the
+        // others -- coordinates of joints outside the marker-ancestor subtree -- are never written (two waves fill a vector)
+        for (int e = threadIdx.x; e < 4 * nqpad; e += blockDim.x) XB[64 + e] = 0.0f;
+        __syncthreads();
+    }
     wave_sync();
 
     PROF_DECL;
@@ -653,14 +659,23 @@ void q_phase_kernel(const QArgs a) {
                         joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa, nx ? crefn : crefa, nx ? gxn : gxa);
                     }
                 } else {
-                    const bool mine_a = cs / CPW == wave, mine_n = (NC + cs) / CPW == wave;  // wave-uniform
-                    if (mine_a || mine_n) {
-                        float *gx = mine_a ? gxa : gxn, *CBx = mine_a ? CBa : CBn;
+                    // Two waves per evaluation: the owner of the role takes every range but the longest and the joints that
+                    // read them, its neighbour (wave ^ 1: a wave of the same half of the roles) the longest range -- all
+                    // sites, for the root -- and the joints on it (the free joint's formulas are the long ones).  No range or
+                    // gradient entry is shared between the two, so they only meet at the barrier that follows anyway.
+                    const int wa = cs / CPW, wn = (NC + cs) / CPW;  // wave-uniform
+                    const bool mine = wa == wave || wn == wave, help = wa == (wave ^ 1) || wn == (wave ^ 1);
+                    if (mine || help) {
+                        const bool first = mine ? wa == wave : wa == (wave ^ 1);
+                        float *gx = first ? gxa : gxn, *CBx = first ? CBa : CBn;
                         const V3 crefx = ld_tpos(CBx + H.c_bx + kXf);
-                        for (int e = lane; e < nqpad; e += 64) gx[e] = 0.0f;
-                        for (int t = lane; t < 6 * H.nrange; t += 64) range_task(t, CBx);
+                        if (mine) { for (int t = 6 + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
+                        else if (lane < 6) range_task(lane, CBx);
                         wave_sync();
-                        for (int j = lane; j < H.naj; j += 64) joint_gradient(j, CBx, crefx, gx);
+                        for (int j = lane; j < H.naj; j += 64) {
+                            const bool on_longest = __builtin_bit_cast(int, jrec[12 * j + 11]) == 0;
+                            if (on_longest != mine) joint_gradient(j, CBx, crefx, gx);
+                        }
                     }
                 }
                 PROF_TICK(5);  // latency mode: gradient pass of the two chosen evaluations (owner waves)
