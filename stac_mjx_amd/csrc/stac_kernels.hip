@@ -146,8 +146,22 @@ void q_phase_kernel(const QArgs a) {
     }
 
     float x[NQR], y[NQR], g[NQR], q0[NQR];
+    // the lane's bounds: from the plan in LDS where registers are short (throughput kernels), in registers in latency mode
+    // (a trip reads them four times per coordinate)
+    constexpr bool BREG = SPEC != 0;
+    float lbr[BREG ? NQR : 1], ubr[BREG ? NQR : 1];
+    if constexpr (BREG) {
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            lbr[r] = e < nq ? lbv[e] : 0.0f;
+            ubr[r] = e < nq ? ubv[e] : 0.0f;
+        }
+    }
+#define LB(r, e) (BREG ? lbr[BREG ? (r) : 0] : lbv[e])
+#define UB(r, e) (BREG ? ubr[BREG ? (r) : 0] : ubv[e])
     // the line-search candidate clip(y - eta * g) is recomputed where it is needed (same bits, fewer registers)
-#define CAND(r, e) clipf(FMA(-eta, g[r], y[r]), lbv[e], ubv[e])
+#define CAND(r, e) clipf(FMA(-eta, g[r], y[r]), LB(r, e), UB(r, e))
     const float eps = 1.1920929e-7f;
 
     // bx[0] = world
@@ -301,7 +315,7 @@ void q_phase_kernel(const QArgs a) {
                 float pt;
                 if (SPEC && st_in == ST_SPEC) {
                     const float ec = eta * spec_pow;  // eta / 2^c (exact)
-                    const float cr = clipf(FMA(-ec, g[r], y[r]), lbv[e], ubv[e]);
+                    const float cr = clipf(FMA(-ec, g[r], y[r]), LB(r, e), UB(r, e));
                     pt = role < NC ? cr : FMA(spec_beta, cr - x[r], cr);
                 } else {
                     pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? CAND(r, e) : x[r]);
@@ -541,7 +555,7 @@ void q_phase_kernel(const QArgs a) {
                 float a0 = 0.0f, a1 = 0.0f;
                 if (e < nq) {
                     if (st_in == ST_VG_X) {
-                        const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
+                        const float d = clipf(x[r] - gnew[r], LB(r, e), UB(r, e)) - x[r];
                         a0 = d * d;
                     } else if (st_in == ST_LS) {
                         const float d = CAND(r, e) - y[r];
@@ -549,7 +563,7 @@ void q_phase_kernel(const QArgs a) {
                         a1 = d * g[r];
                     } else if (SPEC && st_in == ST_SPEC) {
                         const float ec = eta * spec_pow;
-                        const float d = clipf(FMA(-ec, g[r], y[r]), lbv[e], ubv[e]) - y[r];
+                        const float d = clipf(FMA(-ec, g[r], y[r]), LB(r, e), UB(r, e)) - y[r];
                         a0 = d * d;
                         a1 = d * g[r];
                     }
@@ -597,7 +611,7 @@ void q_phase_kernel(const QArgs a) {
                 const int e = r * G + lg;
                 float a0 = 0.0f;
                 if (e < nq) {
-                    const float d = clipf(x[r] - gnew[r], lbv[e], ubv[e]) - x[r];
+                    const float d = clipf(x[r] - gnew[r], LB(r, e), UB(r, e)) - x[r];
                     a0 = d * d;
                 }
                 t0[r] = a0;
@@ -695,8 +709,8 @@ void q_phase_kernel(const QArgs a) {
                     const int e = r * G + lg;
                     float a0 = 0.0f;
                     if (e < nq) {
-                        const float xr = clipf(FMA(-eacc, g[r], y[r]), lbv[e], ubv[e]);
-                        const float d = clipf(xr - gnew[r], lbv[e], ubv[e]) - xr;
+                        const float xr = clipf(FMA(-eacc, g[r], y[r]), LB(r, e), UB(r, e));
+                        const float d = clipf(xr - gnew[r], LB(r, e), UB(r, e)) - xr;
                         a0 = d * d;
                     }
                     t0[r] = a0;
@@ -711,7 +725,7 @@ void q_phase_kernel(const QArgs a) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
-                    const float cr = e < nq ? clipf(FMA(-eacc, g[r], y[r]), lbv[e], ubv[e]) : x[r];
+                    const float cr = e < nq ? clipf(FMA(-eacc, g[r], y[r]), LB(r, e), UB(r, e)) : x[r];
                     const float d = cr - x[r];
                     y[r] = FMA(spec_beta, d, cr);
                     x[r] = cr;
