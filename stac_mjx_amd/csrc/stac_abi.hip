@@ -630,6 +630,7 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     (void)hipGetDevice(&m->device);
     m->dbg.read_env();
     if (build_plan(m, t) != STAC_OK) { delete m; return nullptr; }
+    if (m->dbg.flags >= 0 && (m->dbg.flags & 4)) m->h.fk_uniform = 0;  // A/B switch: run the program step by step through its flags and forms
     const int nb = t->nbody, nj = t->njnt, nq = t->nq, K = t->nsite;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };

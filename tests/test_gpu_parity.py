@@ -136,11 +136,13 @@ def test_q_phase_ik_clips_bit_exact(rodent_setup, rodent_mocap, lanes):
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
 
 
-@pytest.mark.parametrize("flags", ["0", "2"])
-@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("flags", ["0", "2", "4"])
+@pytest.mark.parametrize("lanes", [4, 16, 32])
 def test_q_phase_fk_program_and_level_loop_agree(rodent_setup, fly_setup, rodent_mocap, monkeypatch, flags, lanes):
-    """The kernel has two FK implementations (prefetched step records vs walking the level tables; STAC_HIP_FLAGS
-    bit 1 forces the second, and the fly's 6-wide levels on 4-lane groups force it too): both equal the oracle."""
+    """The kernel has several FK implementations: the step program (one lane or four lanes per position; as ONE
+    straight-line step when the model allows it, else -- or with STAC_HIP_FLAGS bit 2 -- step by step through flags and
+    forms) and the walk over the level tables (bit 1 forces it, and the fly's 6-wide levels on 4-lane groups force it
+    too): all equal the oracle."""
     monkeypatch.setenv("STAC_HIP_FLAGS", flags)
     fs = rodent_setup
     eng, orc = _engine(fs, lanes_per_chain=lanes), _oracle(fs)
