@@ -544,6 +544,10 @@ constexpr int kCus = 256;
 // wavefronts per chain are 6-12 % ahead of eight from 40 to 256 chains and hold twice as many chains: eight are kept
 // behind STAC_HIP_SPECG=64)
 constexpr long kSpec64MaxChains = 0, kSpec32MaxChains = 512;
+// one wavefront per chain: FOUR roles of 16 lanes (two candidates and their momentum points per trip: 1.16 trips per
+// iteration, but the four-lanes-per-position kinematics and fewer rounds in every per-item phase): measured 229 k against
+// 179 k frames/s on 1 000 x 250 clips for eight roles of 8 lanes (which stay behind STAC_HIP_SPECG=8)
+constexpr int kLatG = 16, kLatR = 4;
 // latency mode with 4 roles per chain from this many chains on (never auto-selected below: developer switch STAC_HIP_SPECR)
 constexpr long kSpec4MinChains = 1L << 40;
 
@@ -599,16 +603,16 @@ struct SpecShape { int G, chains_per_block, waves_per_block; long resident; };  
 static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nchains = -1, int nr = 8) {
     constexpr size_t kGranule = 1280;
     SpecShape best{G, 0, 0, 0};
-    if (G == 8) {  // 256-VGPR kernel: two waves per SIMD, eight per CU; 8 / nr chains per wavefront
-        const int cw = 8 / nr;
+    if (G == 8 || G == 16) {  // 256-VGPR kernel: two waves per SIMD, eight per CU; 64 / (G nr) chains per wavefront
+        const int cw = 64 / (G * nr);
         for (int w = 1; w <= 8; ++w) {
-            size_t lds = spec_lds_bytes(h, 8, nkinds, w * cw, nr);
+            size_t lds = spec_lds_bytes(h, G, nkinds, w * cw, nr);
             if (lds > kLdsPerCu) break;
             lds = (lds + kGranule - 1) / kGranule * kGranule;
             const int blocks = std::min((int)(kLdsPerCu / lds), 8 / w);
             const long res = (long)blocks * w * cw * kCus;
-            if (res > best.resident) best = SpecShape{8, w * cw, w, res};
-            if (nchains >= 0 && res >= nchains) return SpecShape{8, w * cw, w, res};  // small workgroups spread over more CUs
+            if (res > best.resident) best = SpecShape{G, w * cw, w, res};
+            if (nchains >= 0 && res >= nchains) return SpecShape{G, w * cw, w, res};  // small workgroups spread over more CUs
         }
         return best;
     }
@@ -653,7 +657,7 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
     {   // hand-off buffer of the straggler hand-off at its maximum size (one entry per wavefront the latency kernel
         // can hold resident), so that no launch ever reallocates (= waits for the device)
-        m->hand_cap = (int)pick_spec_shape(m->h, 8, 1).resident;
+        m->hand_cap = (int)pick_spec_shape(m->h, kLatG, 1, -1, kLatR).resident;
         if (m->hand_cap > 0)
             chk(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)m->hand_cap * (3 * (size_t)m->h.nqpad + 12) * sizeof(float)));
     }
@@ -740,7 +744,7 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
-        const SpecShape ss = pick_spec_shape(m->h, 8, nkinds);  // one chain per wave, eight 8-lane evaluation groups
+        const SpecShape ss = pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR);  // one chain per wave
         if (ss.resident && (long)nchains * 10 <= ss.resident * 23) return 0;
     }
     const QShape s16 = pick_shape(m->h, 16, nkinds);
@@ -778,18 +782,19 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     if (spec) {
         // lanes per evaluation role: with very few chains every chain gets a whole workgroup of 4 or 8 wavefronts
         // (measured, rodent, 250-frame clips: DESIGN.md 2.1), else one wavefront per chain
-        int sg = 8;
+        int sg = kLatG;
         {
             const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(m->h, 32, nkinds);
             if (s64.resident && (long)nchains <= kSpec64MaxChains) sg = 64;
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
         }
-        if (dbg.specg == 8 || dbg.specg == 32 || dbg.specg == 64) sg = dbg.specg;
-        if (m->h.nq > sg * (sg == 8 ? 32 : sg == 32 ? 8 : 4)) sg = 8;  // no instantiation that wide: back to one wave per chain
+        if (dbg.specg == 8 || dbg.specg == 16 || dbg.specg == 32 || dbg.specg == 64) sg = dbg.specg;
+        if (m->h.nq > sg * (sg == 8 ? 32 : sg == 16 ? 16 : sg == 32 ? 8 : 4)) sg = 8;  // no instantiation that wide: back to one wave per chain
         // roles per chain: four (two candidates + their momentum points, two chains per wavefront) once the batch is so
         // large that throughput counts, not the latency of one chain
         int sr = (sg == 8 && (long)nchains >= kSpec4MinChains) ? 4 : 8;
         if (sg == 8 && (dbg.specr == 4 || dbg.specr == 8)) sr = dbg.specr;
+        if (sg == 16) sr = 4;  // four roles of 16 lanes: one chain per wavefront
         const SpecShape sh = pick_spec_shape(m->h, sg, nkinds, nchains, sr);
         if (sh.chains_per_block) {
             const size_t lds = spec_lds_bytes(m->h, sg, nkinds, sh.chains_per_block, sr);
@@ -838,8 +843,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // mean), so the launch would end on a few waves per CU.  Once all but `hcap` chains are done, the rest move to
         // the latency kernel at their next iteration boundary (QArgs::ctl).
         int hcap = 0;
-        if (!a.single && !(a.flags & 3) && m->h.max_width <= 8) {
-            const int spec_cap = (int)pick_spec_shape(m->h, 8, nkinds).resident;
+        if (!a.single && !(a.flags & 3) && m->h.max_width <= kLatG) {
+            const int spec_cap = (int)pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR).resident;
             // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
             if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
             if (dbg.handoff >= 0) hcap = spec_cap ? std::min(dbg.handoff, nchains) : 0;
@@ -853,8 +858,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             const int per_block = sh.wpb * (64 / G), want = dbg.queue;
             if (!a.single && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
         }
-        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= 8 && dbg.handoff < 0) {
-            hcap = std::min((int)pick_spec_shape(m->h, 8, nkinds).resident, nchains / 5);  // with a queue the tail is one round: hand off
+        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= kLatG && dbg.handoff < 0) {
+            hcap = std::min((int)pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR).resident, nchains / 5);  // with a queue the tail is one round: hand off
         }
         hcap = std::min(hcap, m->hand_cap);
         // A group that hands its chain off stops taking chains from the queue, so hand-off must not begin while the
@@ -874,11 +879,11 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             b.resume = 1; b.resume_slots = hcap;
             b.h = m->h;
             b.flags = a.flags & ~2;
-            const SpecShape ss = pick_spec_shape(m->h, 8, nkinds, hcap);
-            b.mb_words = q_mb_words(nkinds, 8);
-            b.h.chain_stride = q_chain_stride(m->h, 8);
+            const SpecShape ss = pick_spec_shape(m->h, kLatG, nkinds, hcap, kLatR);
+            b.mb_words = q_mb_words(nkinds, kLatG);
+            b.h.chain_stride = q_chain_stride(m->h, kLatG);
             int cap2 = 0;
-            e = launch_q_phase(b, 8, ss.waves_per_block, 2, 8, spec_lds_bytes(m->h, 8, nkinds, ss.chains_per_block), s, &cap2);
+            e = launch_q_phase(b, kLatG, ss.waves_per_block, 2, kLatR, spec_lds_bytes(m->h, kLatG, nkinds, ss.chains_per_block, kLatR), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
             if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.waves_per_block);
         }

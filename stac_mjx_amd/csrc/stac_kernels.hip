@@ -58,7 +58,7 @@ namespace stac {
 template <int G, int NQR, int WPE, int SPEC>
 __global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a) {
-    static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 32 || G == 64)) || (SPEC == 4 && G == 8), "speculative mode: 8 (or 4) roles of G lanes");
+    static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 32 || G == 64)) || (SPEC == 4 && (G == 8 || G == 16)), "speculative mode: 8 (or 4) roles of G lanes");
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
     constexpr int NR = SPEC ? SPEC : 1, NC = SPEC ? SPEC / 2 : 1;  // roles per chain, of which candidates
@@ -1025,6 +1025,7 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     }
         STAC_TRY_SPEC(8, 10, 2, 4) STAC_TRY_SPEC(8, 16, 2, 4) STAC_TRY_SPEC(8, 32, 2, 4)
         STAC_TRY_SPEC(8, 10, 2, 8) STAC_TRY_SPEC(8, 16, 2, 8) STAC_TRY_SPEC(8, 32, 2, 8)
+        STAC_TRY_SPEC(16, 5, 2, 4) STAC_TRY_SPEC(16, 8, 2, 4) STAC_TRY_SPEC(16, 16, 2, 4)
         STAC_TRY_SPEC(32, 3, 2, 8) STAC_TRY_SPEC(32, 8, 2, 8)
         STAC_TRY_SPEC(64, 2, 2, 8) STAC_TRY_SPEC(64, 4, 2, 8)
 #undef STAC_TRY_SPEC
