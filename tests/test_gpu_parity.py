@@ -704,12 +704,12 @@ def test_m_partial_with_zero_frames(rodent_setup):
 
 
 # ---- latency mode over 1, 4 and 8 wavefronts per chain ---------------------------------------------------------------
-@pytest.mark.parametrize("specg", ["8", "32", "64"])
+@pytest.mark.parametrize("specg", ["8", "16", "32", "64"])
 def test_latency_mode_wavefronts_per_chain(rodent_setup, fly_setup, mouse_setup, rodent_mocap, monkeypatch, specg):
-    """The eight speculative evaluations of a chain on one wavefront (8 lanes each), on four (32 lanes) or on eight
-    (64 lanes each; roles exchange accept flags, losses and two gradients through LDS, two workgroup barriers per
-    trip): warm-started multi-frame clips of three models, small line-search bound included -- all equal the oracle
-    bit for bit, and each other."""
+    """The speculative evaluations of a chain on one wavefront (eight roles of 8 lanes, or four of 16: the shape of the
+    straggler kernel and of large clip counts), on four (32 lanes each) or on eight (64 lanes each; roles exchange
+    accept flags, losses and two gradients through LDS, two workgroup barriers per trip): warm-started multi-frame
+    clips of three models, small line-search bound included -- all equal the oracle bit for bit, and each other."""
     from oracle import Oracle
     from stac_mjx_amd.engine import Engine
 
@@ -747,7 +747,7 @@ def test_latency_mode_wavefronts_per_chain(rodent_setup, fly_setup, mouse_setup,
                                  do_root_opt=ms.do_root_opt))
 
 
-@pytest.mark.parametrize("specg", ["8", "32", "64"])
+@pytest.mark.parametrize("specg", ["8", "16", "32", "64"])
 def test_latency_mode_chain_queue(rodent_setup, rodent_mocap, monkeypatch, specg):
     """More clips than chain slots in latency mode (forced: 4 slots for 11 clips): the roles of a finished clip -- one
     wavefront, or all wavefronts of the workgroup together -- take the next unstarted clip."""
