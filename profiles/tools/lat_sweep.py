@@ -3,7 +3,7 @@ import sys, os, json, time, subprocess
 import itertools
 res=[]
 for chains in (40, 128, 256, 500, 1000):
-    for sg in (8, 32, 64):
+    for sg in (8, 16, 32, 64):
         env=dict(os.environ, STAC_HIP_SPECG=str(sg), STAC_HIP_SPEC="1")
         out=subprocess.run([sys.executable,"bench.py","--steps","1","--warmup","1","--frames",str(chains*250),"--frames-per-clip","250","--no-cpu-baseline"],env=env,capture_output=True,text=True)
         try:
