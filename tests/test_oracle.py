@@ -303,20 +303,52 @@ def test_ik_clips_threads_and_clip_independence(orc, rodent_setup, rodent_mocap)
     np.testing.assert_array_equal(a["xpos"][1], b["xpos"][0])
 
 
-def test_pg_residuals_in_the_range_the_reference_printed(orc, rodent_setup, rodent_mocap):
-    """Weak corroboration of the jaxopt restatement against a REAL run of the reference: the committed
-    notebook demos/rodent_demo.ipynb (cell 6 output) ran run_stac on the first 10 frames of the same .mat with
-    configs/model/rodent.yaml and printed `Root optimization ... error of 4.31e-05` and, for the first pose pass
-    (before any offset update), `Mean: 3.554e-05 / Standard deviation: 9.48e-06` of the per-frame PG residuals.
-    The trajectories are rounding-sensitive, so only magnitudes can be compared: both below FTOL, mean within 2x."""
+def test_pg_residuals_against_the_run_the_reference_printed(orc, rodent_setup, rodent_mocap):
+    """The one printed run of the reference: demos/rodent_demo.ipynb cell 6 ran run_stac on the first 10 frames of the
+    same .mat with configs/model/rodent.yaml: `Root optimization ... error of 4.3102e-05`, first pose pass (before any
+    offset update) `Mean: 3.5538e-05 / Standard deviation: 9.482e-06` of the per-frame PG residuals.
+
+    tests/tools/jaxopt_variant_sweep.py (table: profiles/r03/jaxopt_variant_sweep.txt) shows that
+    (1) that notebook was produced by OLDER reference source (its print strings and its 40 s iterative offset phase do
+    not exist in the current compute_stac.py); (2) none of 70 variants of the jaxopt details or of the older host rules
+    moves the root residual from 9.5e-5 to 4.3e-5 -- the second root solve is a period-two step-size cycle whose
+    low-phase residuals are ..., 1.20e-4, 9.50e-5, 7.6e-5, 6.4e-5, 6.03e-5 (minimum), so 4.31e-5 cannot be the first
+    value below FTOL on this trajectory; (3) the gap is CONFINED to the root optimisation and the frame that follows it:
+    frames 1-9 of the first pose pass give 3.42e-5 +- 0.78e-5 against the notebook's 3.55e-5 +- 0.95e-5 for all ten.
+    These are the tightest bounds the restatement achieves; they are asserted on the mean AND the std."""
     fs = rodent_setup
     kp = rodent_mocap[:10]
     q, st = orc.root_optimization(kp, fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
-    assert st["error"] <= 1e-4 and st["iter_num"] < 400  # reference: 4.31e-05, i.e. converged below FTOL
+    assert st["iter_num"] == 30 and abs(st["error"] - 9.50e-5) < 1e-6  # reference printed 4.31e-05: unexplained factor 2.2
     out = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
-    mean = float(out["frame_error"].mean())
-    assert 0.5 * 3.554e-05 <= mean <= 2.0 * 3.554e-05, mean
-    assert (out["frame_error"] <= 1e-4).all()  # every frame's last (head) solve converged, like the reference's
+    e = out["frame_error"].astype(np.float64)
+    assert (e <= 1e-4).all()  # every frame's last (head) solve converged, like the reference's
+    # all ten frames: mean within 15 %, std within 2.2x (frame 0, straight after the root optimisation, carries the gap)
+    assert abs(e.mean() / 3.5538e-05 - 1) <= 0.15, e.mean()
+    assert e.std() <= 2.2 * 9.482e-06, e.std()
+    # frames 1-9: mean within 5 %, std within 25 % of the notebook's ten-frame figures
+    assert abs(e[1:].mean() / 3.5538e-05 - 1) <= 0.05, e[1:].mean()
+    assert abs(e[1:].std() / 9.482e-06 - 1) <= 0.25, e[1:].std()
+
+
+def test_variant_sweep_baseline_equals_oracle(orc, rodent_setup, rodent_mocap):
+    """The numpy twin of q_opt_ws inside tests/tools/jaxopt_variant_sweep.py (the loop the variants modify) runs the
+    oracle's trajectory: same iteration counts in the root solves, residuals equal to 1e-3 relative (numpy's dot
+    products sum in another order than the oracle's trees)."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+    import jaxopt_variant_sweep as sweep
+
+    r = sweep.run_variant({}, passes=False)
+    fs = rodent_setup
+    _, st = orc.root_optimization(rodent_mocap[:10], fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
+    assert r["root_iters"][-1] == st["iter_num"]
+    assert abs(r["root_err"] / st["error"] - 1) < 1e-3
+    # a variant that is known to change the trajectory does change it (the switches are live)
+    r2 = sweep.run_variant(dict(eps=0.0), passes=False)
+    assert r2["root_iters"] != r["root_iters"]
 
 
 # ---- optional LM solver (not the reference's algorithm): the oracle side ---------------------------------------------------

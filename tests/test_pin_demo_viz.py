@@ -26,7 +26,9 @@ import pytest
 from helpers import marker_error_mm, oracle_chain_passes, oracle_fit_offsets, pg_residual
 
 STORED_MEAN_MM = 0.919  # mean marker error of the stored reference fit on its 50 frames
-FTOL = 1e-4             # configs/model/rodent.yaml:4
+FTOL = 1e-4             # configs/model/rodent.yaml:4.  demo_viz.p does not record the tolerance it was fitted with (SURVEY.md
+                        # guessed the older default 5e-3); pin 1 below is what shows it was <= 1e-4: a 5e-3 run would leave
+                        # head residuals spread up to 5e-3, the stored ones are <= 1e-4 in 98 % of the frames.
 N_PASSES = 7            # N_ITERS = 6 pose passes + the final one (stac.py:298,331)
 
 
