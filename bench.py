@@ -9,7 +9,10 @@ independent, each rank fits its own shard; no collective on the data path).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 10000] [--frames-per-clip 1]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL only for the timing barrier).
+For N > 1 either launch it under torch.distributed.run yourself (one rank per GPU) or just pass --gpus N: without
+WORLD_SIZE in the environment the script starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child process BEFORE anything touches the GPU and relays rank 0's JSON line.  RCCL carries the timing barrier and the
+max-over-ranks reduction (and, in --mode fit, the 71-float offset-phase all-reduce).
 """
 
 from __future__ import annotations
@@ -132,6 +135,36 @@ def run_fit_mode(args, rank, local_rank, world, dist):
         print(json.dumps(line))
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (never re-exec a process that
+    may have touched the GPU; counting devices does not initialise HIP) and return their exit code.  Rank 0 of the
+    children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+
+    visible = torch.cuda.device_count()
+    if visible < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} requested but only {visible} GPU{'s' if visible != 1 else ''} visible "
+              f"on this node; nothing launched", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def lib_digest() -> str:
+    """What libstac_hip.so was built from (profiles/*.json entries are tied to it)."""
+    from stac_mjx_amd.build import STAMP
+
+    return STAMP.read_text().strip() if STAMP.exists() else ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,9 +187,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run: RCCL barrier + max-over-ranks timing
@@ -223,13 +258,17 @@ def main():
     achieved = frames_step * bytes_frame / (kern_ms * 1e-3) / 1e9
     # algorithmic flops (full-tree constants): value+grad 17.9 kflop, loss 15.9 kflop
     flops = cnt[2] * 17.9e3 + cnt[1] * 15.9e3
-    traffic = None
+    traffic, traffic_note = None, "no rocprofv3 PMC entry for this workload in profiles/traffic.json"
     try:  # HBM bytes per launch measured offline with rocprofv3 PMC passes on this same workload (profiles/)
         for ent in json.load(open(ROOT / "profiles" / "traffic.json"))["entries"]:
-            if ent["frames"] == frames_step and ent["frames_per_clip"] == F and (args.lanes == 0) == (ent["lanes"] == "auto"):
-                traffic = ent["bytes_per_launch"]
-    except Exception:
-        traffic = None
+            if ent["frames"] == frames_step and ent["frames_per_clip"] == F and (args.lanes == 0) == (ent["lanes"] == "auto") \
+                    and ent.get("model", "rodent") == args.model and ent.get("solver", "pg") == args.solver:
+                if ent.get("lib_digest", "") == lib_digest():
+                    traffic, traffic_note = ent["bytes_per_launch"], ent.get("source", "")
+                else:  # the counters were collected on another build of the kernels: not this launch's traffic
+                    traffic_note = f"stale: {ent.get('source', '')} was measured on another build of libstac_hip.so"
+    except (FileNotFoundError, KeyError):
+        pass
     line = {
         "metric": "frames/sec STAC pose-fit (rodent, 23 kp)" if args.model == "rodent" else f"frames/sec STAC pose-fit ({args.model}, {fs.tables.nsite} kp)",
         "value": value, "unit": "frames/s",
@@ -243,6 +282,7 @@ def main():
                         + ("solver=pg (parity mode)" if args.solver == "pg" else "solver=lm (NOT the reference's algorithm; marker-space quality only)"),
             "frames_per_gpu": frames_step, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
             "parallelism": f"clips sharded over {world} GPU(s), no data-path collective",
+            "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
             "iters_per_frame": cnt[0] / frames_step, "ls_evals_per_frame": cnt[1] / frames_step,
             "grad_evals_per_frame": cnt[2] / frames_step,
             "marker_rmse_mm": float(torch.sqrt((err ** 2).mean()).item() * 1e3),
@@ -250,7 +290,8 @@ def main():
             "valu_frac_of_fp32_peak": flops / (kern_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "stac::q_phase_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": "stac::q_phase_kernel",
                      "algorithmic_bytes_per_launch": frames_step * bytes_frame,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_frame": bytes_frame},
     }
@@ -260,6 +301,10 @@ def main():
     try:
         for ent in json.load(open(ROOT / "profiles" / "valu.json"))["entries"]:
             if ent["frames"] == frames_step and ent["frames_per_clip"] == F and args.model == ent.get("model", "rodent") and args.solver == "pg":
+                if ent.get("lib_digest", "") != lib_digest():
+                    # the instruction count belongs to another build of the kernels: do not mix it with this run's time
+                    line["roofline_valu"] = {"stale": True, "source": ent["source"]}
+                    continue
                 evals = float(cnt[1] + cnt[2])  # logical q_loss evaluations of the step (line-search + value-and-gradient)
                 lane_slots = ent["sq_insts_valu"] * 64.0
                 line["roofline_valu"] = {
@@ -269,7 +314,7 @@ def main():
                     "useful_lane_fraction": (flops / 2.0) / lane_slots,  # one FMA = 2 flop per lane-slot at best
                     "valu_issue_busy_frac": ent["sq_insts_valu"] * 2.0 / (1024 * 2.4e9 * kern_ms * 1e-3),
                     "note": "wave64 VALU instruction = 2 issue cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz; busy = issued / available"}
-    except Exception:
+    except (FileNotFoundError, KeyError):
         pass
     if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and F == 1 and not args.no_extras:
         # BASELINE configs[1] with the reference's DEFAULT chaining (configs/stac/stac.yaml:9, n_frames_per_clip = 250):

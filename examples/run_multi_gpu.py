@@ -9,12 +9,14 @@ What runs (BASELINE.json configs[3], scaled by the arguments):
   1. ``run_stac`` with ``stac.fit_frames_per_clip`` (engine extension): the fit frames are cut into clips, the clips
      are sharded over the ranks, and every calibration iteration combines the 3K + 2 offset-phase sums
      (``stac_mjx/stac_core.py:157-160`` summed over ranks) with ONE collective on the device buffers
-     (``dist.all_reduce_partial``: all-gather + fixed-order sum, bitwise reproducible; ``--ring`` uses a plain
-     ``all_reduce``).  That is the only data-path collective of the engine.
+     (``dist.all_reduce_partial``: all-gather + fixed-order sum, bitwise reproducible).  That is the only data-path
+     collective of the engine.
   2. ``ik_only`` of a long synthetic recording: contiguous blocks of clips per rank, no communication; the results
-     are gathered to rank 0 (``stac.gather = rank0``), which writes the output file.
+     are gathered to rank 0 (``stac.gather = rank0``), which writes the output file; ``--gather none`` (or ``auto`` above
+     1 GiB of outputs) makes every rank write its own shard file plus a manifest instead.
 
-The process group is created with ``device_id`` BEFORE anything touches the GPU.  Data: synthetic motion
+The process group is created with ``device_id`` right after ``torch.cuda.set_device`` and before any kernel, copy or
+allocation on the GPU.  Data: synthetic motion
 (stac_mjx_amd/synth.py; no dataset can be fetched here), 1 mm keypoint noise, marker offsets perturbed by 2 mm.
 """
 
@@ -42,6 +44,7 @@ def main():
     ap.add_argument("--frames-per-clip", type=int, default=250)
     ap.add_argument("--n-iters", type=int, default=6)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--gather", default="rank0", choices=["rank0", "all", "none", "auto"])
     ap.add_argument("--backend", default="nccl", help="nccl = RCCL over xGMI (GPUs); gloo for a CPU-side smoke run of the plumbing")
     args = ap.parse_args()
 
@@ -87,7 +90,7 @@ def main():
     cfg = validate_config({"model": dict(mcfg), "stac": dict(
         fit_offsets_path="fit_offsets.h5", ik_only_path="ik_only.h5", data_path="-", continuous=False,
         n_fit_frames=args.fit_frames, skip_fit_offsets=False, skip_ik_only=False, infer_qvels=False,
-        n_frames_per_clip=args.frames_per_clip, fit_frames_per_clip=args.fit_frames_per_clip, gather="rank0",
+        n_frames_per_clip=args.frames_per_clip, fit_frames_per_clip=args.fit_frames_per_clip, gather=args.gather,
         mujoco=dict(solver="newton", iterations=1, ls_iterations=4))})
     torch.cuda.synchronize()
     dist.barrier()
@@ -98,7 +101,7 @@ def main():
     t_all = time.perf_counter() - t0
     if rank == 0:
         _, fit = io.load_stac_data(fit_path)
-        _, ik = io.load_stac_data(ik_path)
+        _, ik = io.load_sharded_stac_data(ik_path) if str(ik_path).endswith(".manifest.json") else io.load_stac_data(ik_path)
         err = np.linalg.norm(ik.marker_sites - ik.kp_data.reshape(len(ik.kp_data), -1, 3), axis=-1).mean() * 1e3
         print(json.dumps({
             "world_size": world, "backend": tdist.get_backend(), "fit_frames": int(fit.qpos.shape[0]),

@@ -10,7 +10,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
   rm -rf /tmp/rq_${tag}_$i
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/rq_${tag}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /tmp/rq_${tag}_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/rq_${tag}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /tmp/rq_${tag}_$i.log 2>&1
   python3 $R/profiles/tools/pmc_summary.py /tmp/rq_${tag}_$i q_phase_kernel > $OUT/pass$i.json
 done
 python3 - <<PY

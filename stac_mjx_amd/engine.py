@@ -14,7 +14,9 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .build import LIB
+from .build import LIB, STAMP, source_digest
+
+ABI_VERSION = 3  # include/stac_hip.h: STAC_HIP_ABI_VERSION
 
 _i32p = C.POINTER(C.c_int32)
 _f32p = C.POINTER(C.c_float)
@@ -62,7 +64,17 @@ def load_library(path: Path | None = None):
     p = Path(path) if path else Path(os.environ.get("STAC_HIP_LIB", LIB))  # env: diagnostic builds only
     if not p.exists():
         raise StacHipError(f"HIP extension not built: {p} is missing (run `python -m stac_mjx_amd.build`)")
+    if p == LIB and STAMP.exists() and STAMP.read_text().strip() != source_digest():
+        # the library is git-ignored and travels separately from the sources: never call a stale one with today's
+        # argument layout (python -m stac_mjx_amd.build rebuilds; STAC_HIP_LIB selects a diagnostic build explicitly)
+        raise StacHipError(f"{p} was built from other sources than the ones in this tree (stamp {STAMP.name} differs): "
+                           "rebuild with `python -m stac_mjx_amd.build`")
     lib = C.CDLL(str(p))
+    lib.stac_abi_version.restype = C.c_int32
+    got = int(lib.stac_abi_version())
+    if got != ABI_VERSION:
+        raise StacHipError(f"{p} exports ABI version {got}, this binding needs {ABI_VERSION}: rebuild with "
+                           "`python -m stac_mjx_amd.build`")
     lib.stac_last_error.restype = C.c_char_p
     lib.stac_model_create.restype = C.c_void_p
     lib.stac_model_create.argtypes = [C.POINTER(StacModelTables)]

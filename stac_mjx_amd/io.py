@@ -177,3 +177,52 @@ def load_stac_data(file_path):
         kp_names=names(d["kp_names"]), names_qpos=names(d["names_qpos"]), names_xpos=names(d["names_xpos"]),
         kp_data=d["kp_data"], marker_sites=d["marker_sites"], offsets=d["offsets"], qpos=d["qpos"],
         qvel=d["qvel"], xpos=d["xpos"], xquat=d["xquat"])  # fmt: skip
+
+
+# ---- per-rank shard files of a multi-GPU ik_only run (engine extension; main.run_stac with stac.gather = none / auto) ----
+def shard_path(file_path, rank: int, world_size: int) -> Path:
+    """``ik_only.h5`` -> ``ik_only.rank003-of-008.h5``."""
+    file_path = Path(file_path)
+    return file_path.with_name(f"{file_path.stem}.rank{rank:03d}-of-{world_size:03d}{file_path.suffix}")
+
+
+def manifest_path(file_path) -> Path:
+    file_path = Path(file_path)
+    return file_path.with_name(file_path.stem + ".manifest.json")
+
+
+def write_manifest(manifest, file_path, world_size: int, n_clips: int, n_frames_per_clip: int) -> Path:
+    """Which rank's file holds which clips (contiguous blocks, ``dist.shard_range``)."""
+    import json
+
+    from .dist import shard_range
+
+    shards = []
+    for r in range(world_size):
+        lo, hi = shard_range(n_clips, r, world_size)
+        shards.append(dict(rank=r, file=resolve_output_path(shard_path(file_path, r, world_size)).name, clip_lo=lo, clip_hi=hi,
+                           frame_lo=lo * n_frames_per_clip, frame_hi=hi * n_frames_per_clip))
+    doc = dict(format="stac_mjx_amd.sharded_ik_only/1", world_size=world_size, n_clips=n_clips,
+               n_frames_per_clip=n_frames_per_clip, shards=shards)
+    Path(manifest).write_text(json.dumps(doc, indent=1) + "\n")
+    return Path(manifest)
+
+
+def load_sharded_stac_data(manifest):
+    """Read a sharded run back as ONE ``StacData`` (frame order = the order of an unsharded run)."""
+    import json
+
+    manifest = Path(manifest)
+    doc = json.loads(manifest.read_text())
+    cfg, parts = None, []
+    for sh in doc["shards"]:
+        cfg, d = load_stac_data(manifest.parent / sh["file"])
+        if d.qpos.shape[0] != sh["frame_hi"] - sh["frame_lo"]:
+            raise ValueError(f"shard {sh['file']} holds {d.qpos.shape[0]} frames, the manifest says {sh['frame_hi'] - sh['frame_lo']}")
+        parts.append(d)
+    cat = lambda name: np.concatenate([getattr(p, name) for p in parts if getattr(p, name).size], axis=0) if any(
+        getattr(p, name).size for p in parts) else np.array([])  # noqa: E731
+    first = parts[0]
+    return cfg, StacData(qpos=cat("qpos"), xpos=cat("xpos"), xquat=cat("xquat"), marker_sites=cat("marker_sites"),
+                         offsets=first.offsets, kp_data=cat("kp_data"), names_qpos=first.names_qpos,
+                         names_xpos=first.names_xpos, kp_names=first.kp_names, qvel=cat("qvel"))

@@ -64,20 +64,60 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
     # continuous / n_frames_per_clip / infer_qvels below and is what the ik_only file records (the Stac object
     # itself keeps the caller's config, also as in the reference)
     cfg, fit_data = io.load_stac_data(fit_offsets_path)
+    rank, world_size = dist.world()
+    F = int(cfg.stac.n_frames_per_clip)
+    sharded = world_size > 1 and _ik_output_mode(stac.cfg, kp_data.shape[0], stac) == "none"
+    if sharded:
+        if cfg.stac.continuous:
+            raise ValueError("stac.gather = none writes per-rank shards, but stac.continuous cross-fades neighbouring "
+                             "clips across shard borders: use gather = rank0 (or all) for continuous runs")
+        stac.cfg.stac["gather"] = "none"  # an "auto" decision becomes explicit for Stac._gather
     ik_data = stac.ik_only(kp_data, fit_data.offsets)
-    if dist.world()[0] != 0 and str(stac.cfg.stac.get("gather", "rank0") or "rank0") != "all":
+    if rank != 0 and not sharded and str(stac.cfg.stac.get("gather", "rank0") or "rank0") != "all":
         dist.barrier()  # this rank holds its own shard only: rank 0 post-processes and writes the gathered result
         return fit_offsets_path, io.resolve_output_path(ik_only_path)
     if cfg.stac.continuous:
-        ik_data = utils.handle_edge_effects(ik_data, cfg.stac.n_frames_per_clip)
+        ik_data = utils.handle_edge_effects(ik_data, F)
     print(f"Final qpos shape: {ik_data.qpos.shape}")
-    if cfg.stac.infer_qvels:  # main.py:118-133: per clip of n_frames_per_clip frames
-        batched = ik_data.qpos.reshape((-1, cfg.stac.n_frames_per_clip, ik_data.qpos.shape[-1]))
+    if cfg.stac.infer_qvels and ik_data.qpos.shape[0]:  # main.py:118-133: per clip of n_frames_per_clip frames
+        batched = ik_data.qpos.reshape((-1, F, ik_data.qpos.shape[-1]))
         qvels = [utils.compute_velocity_from_kinematics(c, dt=stac._timestep, freejoint=stac._freejoint) for c in batched]
         ik_data.qvel = np.stack(qvels).reshape(-1, qvels[0].shape[-1])
-    if dist.world()[0] == 0:
+    if sharded:
+        # every rank writes ITS clips under a shard name (never a partial result under the full-run name); rank 0 adds
+        # the manifest that io.load_sharded_stac_data() reads the run back through
+        n_clips = kp_data.shape[0] // F
+        lo, hi = dist.shard_range(n_clips)
+        shard = io.shard_path(ik_only_path, rank, world_size)
+        io.save_data_to_h5(config=cfg, file_path=shard, **ik_data.as_dict())
+        dist.barrier()
+        manifest = io.manifest_path(ik_only_path)
+        if rank == 0:
+            io.write_manifest(manifest, ik_only_path, world_size, n_clips, F)
+        dist.barrier()
+        print(f"Saved ik_only shard {io.resolve_output_path(shard)} (clips {lo}:{hi}); manifest {manifest}. "
+              f"Finished in {(time.time() - start) / 60:.2f} minutes")
+        return fit_offsets_path, manifest
+    if rank == 0:
         io.save_data_to_h5(config=cfg, file_path=ik_only_path, **ik_data.as_dict())
     ik_only_path = io.resolve_output_path(ik_only_path)
     dist.barrier()
     print(f"Saved ik_only to {ik_only_path}. Finished in {(time.time() - start) / 60:.2f} minutes")
     return fit_offsets_path, ik_only_path
+
+
+GATHER_AUTO_MAX_BYTES = 1 << 30  # above this much output a multi-GPU run keeps per-rank shard files ("auto")
+
+
+def _ik_output_mode(cfg, n_frames: int, stac) -> str:
+    """``stac.gather`` for the ik_only outputs: "rank0" | "all" | "none" | "auto" (default).  "auto" gathers to rank 0
+    while the packed outputs (qpos, xpos, xquat, marker_sites, kp_data; 2 728 B per rodent frame) stay below
+    ``stac.gather_max_bytes`` (default 1 GiB) and writes per-rank shards above: a 1 M-frame run is 2.7 GB that a
+    padded gather would stage on rank 0's GPU for nothing."""
+    mode = str(cfg.stac.get("gather", "auto") or "auto")
+    if mode != "auto":
+        return mode
+    t = stac.setup.tables
+    per_frame = 4 * (t.nq + 7 * t.nbody + 6 * t.nsite)
+    limit = int(cfg.stac.get("gather_max_bytes", GATHER_AUTO_MAX_BYTES) or GATHER_AUTO_MAX_BYTES)
+    return "rank0" if n_frames * per_frame <= limit else "none"

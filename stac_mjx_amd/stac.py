@@ -161,8 +161,10 @@ class Stac:
         clip, the other ranks keep (and return) their own shard; "all" -- every rank gets every clip (small runs,
         tests); "none" -- every rank keeps its shard.  Returns (results, the keypoint clips that go with them)."""
         mode = str(self.cfg.stac.get("gather", "rank0") or "rank0")
+        if mode == "auto":  # run_stac resolves "auto" by output size before it calls ik_only; direct callers get rank0
+            mode = "rank0"
         if mode not in ("rank0", "all", "none"):
-            raise ValueError(f"stac.gather must be rank0, all or none, not {mode!r}")
+            raise ValueError(f"stac.gather must be auto, rank0, all or none, not {mode!r}")
         tensors = {k: v for k, v in res.items() if isinstance(v, torch.Tensor)}
         if mode == "all":
             return {k: dist.all_gather_clips(v, n_clips) for k, v in tensors.items()}, kp_clips

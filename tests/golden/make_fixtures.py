@@ -22,6 +22,9 @@ Fixtures are DATA only (inputs / expected outputs / compiled model tables), no r
                             fruitfly_force_free.xml + configs/model/fly_tethered.yaml (BASELINE config 5).
   mouse_tables.npz / mouse_model_cfg.json
                             mouse_with_meshes.xml + configs/model/mouse.yaml (nq = 230, K = 34).
+  mouse_mocap_200.npy       the first 200 frames of tests/data/test_mouse_mocap_3600_frames.h5 through load_data
+                            semantics (configs/model/mouse.yaml): float32 [200, 102], KEYPOINT_MODEL_PAIRS order.  Read
+                            under /opt/conda/bin/python3.9 (the interpreter of this image that has h5py).
   oracle_regress.npz        outputs of THIS repo's oracle on a few real frames (regression pin of the
                             oracle itself; not a reference pin).
 """
@@ -111,6 +114,22 @@ def main():
     build_fit_setup(ref / mouse["MJCF_PATH"], mouse, mouse_names).tables.save(HERE / "mouse_tables.npz")
     with open(HERE / "mouse_model_cfg.json", "w") as fh:
         json.dump(mouse, fh, indent=1)
+
+    # 4c. real mouse mocap (h5py lives in the image's python3.9 only: run load_data there)
+    import subprocess
+
+    h5py_python = "/opt/conda/bin/python3.9"
+    code = (
+        "import sys, json; sys.path.insert(0, sys.argv[1]); import numpy as np\n"
+        "from stac_mjx_amd import io; from stac_mjx_amd.config import validate_config\n"
+        "m = json.load(open(sys.argv[1] + '/tests/golden/mouse_model_cfg.json'))\n"
+        "cfg = validate_config({'model': m, 'stac': dict(fit_offsets_path='f.h5', ik_only_path='i.h5', continuous=False,\n"
+        "    data_path='tests/data/test_mouse_mocap_3600_frames.h5', n_fit_frames=1, skip_fit_offsets=False,\n"
+        "    skip_ik_only=False, infer_qvels=False, n_frames_per_clip=1, mujoco=dict(solver='newton', iterations=1, ls_iterations=4))})\n"
+        "kp, names = io.load_data(cfg, sys.argv[2])\n"
+        "assert kp.shape == (3600, 102) and names == list(m['KEYPOINT_MODEL_PAIRS'].keys())\n"
+        "np.save(sys.argv[3], kp[:200])\n")
+    subprocess.run([h5py_python, "-c", code, str(ROOT), str(ref), str(HERE / "mouse_mocap_200.npy")], check=True)
 
     # 5. oracle regression pin -------------------------------------------------------------------
     from oracle import Oracle

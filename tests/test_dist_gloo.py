@@ -99,3 +99,101 @@ def test_single_process_helpers_are_identity():
     assert dist.world() == (0, 1) and dist.shard_range(7) == (0, 7)
     t = torch.arange(6.0)
     assert torch.equal(dist.all_reduce_partial(t), t) and torch.equal(dist.all_gather_clips(t, 6), t)
+
+
+# ---- per-rank shard files instead of a padded gather (run_stac, stac.gather = none / auto) -----------------------------
+def _shard_worker(rank, world, port, tmp, mode, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import json
+
+    import torch.distributed as tdist
+
+    from stac_mjx_amd import dist, io, main
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.fit_model import finish_fit_setup
+    from stac_mjx_amd.mjcf import ModelTables
+
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mcfg = json.load(open(GOLDEN / "rodent_model_cfg.json"))
+        fs = finish_fit_setup(ModelTables.load(GOLDEN / "rodent_tables.npz"), mcfg, list(mcfg["KEYPOINT_MODEL_PAIRS"].keys()))
+        F, n_clips = 2, 5  # ragged: rank 0 owns 3 clips, rank 1 owns 2
+        stac_cfg = dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="d.mat", continuous=False, n_fit_frames=4,
+                        skip_fit_offsets=True, skip_ik_only=False, infer_qvels=True, n_frames_per_clip=F,
+                        mujoco=dict(solver="newton", iterations=1, ls_iterations=4))
+        stac_cfg.update(mode)
+        cfg = validate_config({"model": dict(mcfg), "stac": stac_cfg})
+        z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
+        names = dict(kp_names=fs.kp_names, names_qpos=fs.part_names, names_xpos=fs.tables.body_names)
+        if rank == 0:
+            io.save_data_to_h5(config=cfg, file_path=f"{tmp}/fit.h5", kp_data=z(4, 69), marker_sites=z(4, 23, 3),
+                               offsets=np.full((23, 3), 0.25, np.float32), qpos=z(4, 74), xpos=z(4, 67, 3),
+                               xquat=z(4, 67, 4), qvel=np.array([]), **names)
+        dist.barrier()
+        kp_all = np.arange(n_clips * F * 69, dtype=np.float32).reshape(n_clips * F, 69)
+
+        class ShardStac:  # what Stac.ik_only returns under gather = none: this rank's clips only
+            _timestep, _freejoint = 0.002, True
+
+            def __init__(self, xml, cfg, kp_names, **kw):
+                self.cfg = cfg
+                self.setup = fs
+
+            def ik_only(self, kp, offsets):
+                mode_now = str(self.cfg.stac.get("gather", "rank0"))
+                lo, hi = dist.shard_range(n_clips) if mode_now == "none" else (0, n_clips)
+                n = (hi - lo) * F
+                qp = z(n, 74)
+                qp[:, 3] = 1.0
+                qp[:, 0] = np.arange(lo * F, hi * F)  # frame id in the root x coordinate
+                return io.StacData(qpos=qp, xpos=z(n, 67, 3), xquat=z(n, 67, 4), marker_sites=z(n, 23, 3),
+                                   offsets=np.asarray(offsets), kp_data=kp[lo * F : hi * F], **names)
+
+        main.Stac = ShardStac
+        _, ik_path = main.run_stac(cfg, kp_all, fs.kp_names, base_path=tmp)
+        q.put((rank, str(ik_path)))
+    finally:
+        tdist.destroy_process_group()
+
+
+def _run_sharded(tmp_path, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, str(tmp_path), mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_run_stac_writes_per_rank_shards_and_a_manifest(tmp_path):
+    """stac.gather = none: no rank writes a partial result under the full-run name; every rank writes its clip block
+    (ragged: 3 + 2 clips), rank 0 the manifest; io.load_sharded_stac_data gives the frames back in run order."""
+    import json
+
+    from stac_mjx_amd import io
+
+    paths = _run_sharded(tmp_path, dict(gather="none"))
+    assert paths[0] == paths[1] and paths[0].endswith("ik.manifest.json")
+    assert not (tmp_path / "ik.h5").exists() and not (tmp_path / "ik.npz").exists()
+    doc = json.loads((tmp_path / "ik.manifest.json").read_text())
+    assert [(s["clip_lo"], s["clip_hi"]) for s in doc["shards"]] == [(0, 3), (3, 5)]
+    for s in doc["shards"]:
+        assert (tmp_path / s["file"]).exists() and f"rank{s['rank']:03d}-of-002" in s["file"]
+    cfg, data = io.load_sharded_stac_data(paths[0])
+    np.testing.assert_array_equal(data.qpos[:, 0], np.arange(10))
+    np.testing.assert_array_equal(data.kp_data, np.arange(10 * 69, dtype=np.float32).reshape(10, 69))
+    assert data.qvel.shape == (10, 73) and np.all(data.offsets == 0.25)
+
+
+def test_run_stac_auto_gather_switches_on_output_size(tmp_path):
+    """"auto" (the default): small runs gather to rank 0 and write ONE file; above stac.gather_max_bytes, shards."""
+    small = _run_sharded(tmp_path / "a", dict()) if (tmp_path / "a").mkdir() is None else None
+    assert small[0].endswith(("ik.h5", "ik.npz")) and not (tmp_path / "a" / "ik.manifest.json").exists()
+    big = _run_sharded(tmp_path / "b", dict(gather_max_bytes=1000)) if (tmp_path / "b").mkdir() is None else None
+    assert big[0].endswith("ik.manifest.json")

@@ -122,3 +122,98 @@ def test_config5_fruitfly_one_gpu_share(fly_setup):
         np.testing.assert_array_equal(q[c], ref["qpos"][i])
         np.testing.assert_array_equal(res["xquat"][c].cpu().numpy(), ref["xquat"][i])
         np.testing.assert_array_equal(res["counters"][c].cpu().numpy().astype(np.uint32), ref["counters"][i])
+
+
+def test_config4_one_gpu_share_125k_frames(rodent_setup, rodent_cfg):
+    """BASELINE configs[3] (1 M frames of ik_only over 8 GPUs at the reference's default chaining): ONE GPU's share,
+    125 000 frames = 500 clips x 250 frames, at full size on the HIP path -- run-to-run determinism, box constraints,
+    kinematic consistency of the recorded markers, fit quality, and three sampled clips bit-equal to the oracle."""
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.synth import synth_keypoints, synth_offsets
+
+    fs = rodent_setup
+    tol, maxiter = float(rodent_cfg["FTOL"]), int(rodent_cfg["N_ITER_Q"])
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=tol, maxiter=maxiter)
+    off = synth_offsets(fs)
+    eng.set_site_pos(off)
+    fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
+    kp, _ = synth_keypoints(fs, fk, 500, 250, seed=21, noise_seed=22)
+    kp_d = torch.as_tensor(kp).to(eng.device)
+    args = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims,
+                do_root_opt=fs.do_root_opt, want_bodies=False)
+    res = eng.q_phase(kp_d, **args)
+    q = res["qpos"].cpu().numpy()
+    assert q.shape == (500, 250, 74) and np.isfinite(q).all()
+    res2 = eng.q_phase(kp_d, **args)
+    for k in ("qpos", "frame_error", "counters", "marker_sites", "carry_qpos"):
+        assert torch.equal(res[k], res2[k]), k
+    fin = np.isfinite(fs.lb) & np.isfinite(fs.ub)
+    assert (q[..., fin] >= fs.lb[fin] - 1e-6).all() and (q[..., fin] <= fs.ub[fin] + 1e-6).all()
+    np.testing.assert_allclose(np.linalg.norm(q[..., 3:7], axis=-1), 1.0, atol=1e-5)  # written-back unit quaternions
+    ms = res["marker_sites"].cpu().numpy()
+    assert marker_error_mm(ms, kp) < 2.0  # 1 mm keypoint noise
+    assert (res["frame_error"].cpu().numpy() > 0).all() and (res["counters"][..., 3].cpu().numpy() == 6).all()
+    # recorded markers are FK(recorded qpos), bit for bit, on a strided sample of all 125 000 poses
+    flat_q = res["qpos"].reshape(-1, 74)[::997]
+    again = eng.fk(flat_q, want=("site_xpos",))["site_xpos"]
+    assert torch.equal(again, res["marker_sites"].reshape(-1, 23, 3)[::997])
+    orc = _oracle(fs, tol=tol, maxiter=maxiter)
+    orc.set_site_pos(off)
+    sel = [0, 251, 499]
+    ref = orc.ik_clips(kp[sel], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, want_bodies=False)
+    for i, c in enumerate(sel):
+        np.testing.assert_array_equal(q[c], ref["qpos"][i])
+        np.testing.assert_array_equal(ms[c], ref["marker_sites"][i])
+        np.testing.assert_array_equal(res["frame_error"][c].cpu().numpy(), ref["frame_error"][i])
+        np.testing.assert_array_equal(res["counters"][c].cpu().numpy().astype(np.uint32), ref["counters"][i])
+
+
+def test_mouse_real_recording_full_solves(mouse_setup):
+    """The mouse model (nq = 230, 85 tree levels, K = 34) on REAL frames (the first 200 of the reference's
+    tests/data/test_mouse_mocap_3600_frames.h5, tests/golden/mouse_mocap_200.npy) at the config's own N_ITER_Q = 400 and
+    FTOL with root optimisation: 8 clips x 2 frames against the oracle at tolerance 0 at three lane widths, then a
+    2 000-frame property run (the 200 real frames, ten times with 0.2 mm of seeded jitter)."""
+    from stac_mjx_amd.engine import Engine
+
+    fs = mouse_setup
+    with open(GOLDEN / "mouse_model_cfg.json") as fh:
+        mcfg = json.load(fh)
+    tol, maxiter = float(mcfg["FTOL"]), int(mcfg["N_ITER_Q"])
+    assert maxiter == 400 and fs.do_root_opt
+    real = np.load(GOLDEN / "mouse_mocap_200.npy")
+    assert real.shape == (200, 102)
+    kp = real[::12][:16].reshape(8, 2, 102)  # 8 clips of 2 frames, spread over the recording
+    orc = _oracle(fs, tol=tol, maxiter=maxiter)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, do_root_opt=True)
+    assert ref["counters"][..., 0].max() >= 400  # real data: the full-body solves run to the iteration cap
+    args = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims,
+                do_root_opt=True)
+    for lanes in (0, 16, 64):
+        eng = Engine(fs.tables, fs.lb, fs.ub, tol=tol, maxiter=maxiter, lanes_per_chain=lanes)
+        res = eng.q_phase(kp, **args)
+        np.testing.assert_array_equal(res["qpos"].cpu().numpy(), ref["qpos"])
+        np.testing.assert_array_equal(res["marker_sites"].cpu().numpy(), ref["marker_sites"])
+        np.testing.assert_array_equal(res["xpos"].cpu().numpy(), ref["xpos"])
+        np.testing.assert_array_equal(res["frame_error"].cpu().numpy(), ref["frame_error"])
+        np.testing.assert_array_equal(res["counters"].cpu().numpy().astype(np.uint32), ref["counters"])
+        eng.close()
+    # ---- 2 000 frames, one frame per clip: properties at a size the oracle would need minutes for ----------------------
+    rng = np.random.default_rng(5)
+    big = np.concatenate([real + (rng.normal(0, 2e-4, real.shape).astype(np.float32) if r else 0) for r in range(10)])
+    big = big.reshape(2000, 1, 102).astype(np.float32)
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=tol, maxiter=maxiter)
+    res = eng.q_phase(big, **args)
+    res2 = eng.q_phase(big, **args)
+    q = res["qpos"].cpu().numpy()
+    assert np.isfinite(q).all()
+    for k in ("qpos", "frame_error", "counters", "marker_sites"):
+        assert torch.equal(res[k], res2[k]), k
+    fin = np.isfinite(fs.lb) & np.isfinite(fs.ub)
+    assert (q[..., fin] >= fs.lb[fin] - 1e-6).all() and (q[..., fin] <= fs.ub[fin] + 1e-6).all()
+    # the un-jittered first 200 clips are the real frames: those that were also in the 8 x 2 sample start identically
+    np.testing.assert_array_equal(q[0, 0], ref["qpos"][0, 0])
+    again = eng.fk(res["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
+    assert torch.equal(again, res["marker_sites"].reshape(-1, fs.tables.nsite, 3))
+    # the fit reduces the marker error of the root-only pose by a wide margin on every frame
+    e_fit = np.linalg.norm(res["marker_sites"].cpu().numpy() - big.reshape(2000, 1, 34, 3), axis=-1).mean(axis=(1, 2))
+    assert np.median(e_fit) < 0.03, np.median(e_fit)  # the oracle reaches 0.017 on the sampled real frames

@@ -1,5 +1,6 @@
 """Host logic on CPU: config, io, batching, PRNG, seam protocol, C-ABI symbols (no GPU compute)."""
 
+import os
 import re
 import types
 
@@ -541,3 +542,90 @@ def test_h5_writer_and_reader_executed_with_h5py(tmp_path):
         for k in ("kp_data", "marker_sites", "offsets", "qpos", "xpos", "xquat"):
             assert d[k][0] == "float32" and d[k][2] == "gzip", (k, d[k])
     assert out["ik"]["qvel"] == ["float32", [3, 73], "gzip"] and out["fit"]["qvel"][1] == [0]
+
+
+# ---- library loading guards and the bench launcher (no GPU needed) -------------------------------------------------------
+def test_load_library_refuses_a_stale_or_wrong_abi_library(monkeypatch):
+    """The .so is git-ignored and travels apart from the sources: a library built from other sources, or one that
+    exports another ABI version, must raise instead of being called with today's argument layout."""
+    from stac_mjx_amd import engine
+
+    engine.load_library()  # the in-tree build loads
+    monkeypatch.setattr(engine, "_LIB", None)
+    monkeypatch.setattr(engine, "source_digest", lambda: "0" * 64)
+    with pytest.raises(engine.StacHipError, match="other sources"):
+        engine.load_library()
+    monkeypatch.undo()
+    monkeypatch.setattr(engine, "_LIB", None)
+    monkeypatch.setattr(engine, "ABI_VERSION", 99)
+    with pytest.raises(engine.StacHipError, match="ABI version"):
+        engine.load_library()
+
+
+def test_bench_gpus_n_launches_itself_or_says_why_not():
+    """`python bench.py --gpus 2` outside torchrun (how the driver calls it): the parent starts the ranks as child
+    processes before touching the GPU; with fewer GPUs than asked it says so and exits non-zero without hanging."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "GPU" in r.stderr and "visible" in r.stderr and r.stdout.strip() == ""
+    env["WORLD_SIZE"] = "1"  # a launcher that disagrees with --gpus is an error too, not a silent 1-GPU run
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+# ---- the .nwb / .h5 INPUT loaders, executed on the reference's own data (stac_mjx/io.py:127-170) ------------------------
+_LOADER_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from stac_mjx_amd import io
+from stac_mjx_amd.config import validate_config
+ref = sys.argv[2]
+def cfg_for(model_json, data_path):
+    m = json.load(open(sys.argv[1] + "/tests/golden/" + model_json))
+    return m, validate_config({"model": m, "stac": dict(fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path=data_path,
+        continuous=False, n_fit_frames=3, skip_fit_offsets=False, skip_ik_only=False, infer_qvels=True, n_frames_per_clip=3,
+        mujoco=dict(solver="newton", iterations=1, ls_iterations=4))})
+m, c = cfg_for("rodent_model_cfg.json", "tests/data/test_rodent_mocap_1000_frames.nwb")
+nwb, names_nwb = io.load_data(c, ref)
+_, c = cfg_for("rodent_model_cfg.json", "tests/data/test_rodent_mocap_1000_frames.mat")
+mat, names_mat = io.load_data(c, ref)
+mm, c = cfg_for("mouse_model_cfg.json", "tests/data/test_mouse_mocap_3600_frames.h5")
+h5, names_h5 = io.load_data(c, ref)
+golden = np.load(sys.argv[1] + "/tests/golden/rodent_mocap_1000.npy")
+mouse_golden = np.load(sys.argv[1] + "/tests/golden/mouse_mocap_200.npy")
+print(json.dumps(dict(
+    nwb_shape=list(nwb.shape), mat_shape=list(mat.shape), h5_shape=list(h5.shape), nwb_names=names_nwb, h5_names=names_h5,
+    rodent_pairs=list(m["KEYPOINT_MODEL_PAIRS"].keys()), mouse_pairs=list(mm["KEYPOINT_MODEL_PAIRS"].keys()),
+    nwb_equals_mat=bool(np.array_equal(nwb, mat)), mat_equals_fixture=bool(np.array_equal(mat, golden)),
+    h5_equals_fixture=bool(np.array_equal(h5[:200], mouse_golden)), dtypes=[str(nwb.dtype), str(h5.dtype)],
+    h5_finite=bool(np.isfinite(h5).all()))))
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(_H5_PY) or not REFERENCE.exists(),
+                    reason="needs the image's h5py interpreter and the reference's test data (build container only)")
+def test_nwb_and_h5_input_loaders_on_the_reference_data(tmp_path):
+    """N1: `load_nwb` / `load_h5` through `load_data`, on tests/data/test_rodent_mocap_1000_frames.nwb and
+    test_mouse_mocap_3600_frames.h5, with the expectations of the reference's tests/test_io.py:93-173: shapes
+    (1000, 69) and (3600, 102), keypoint order == KEYPOINT_MODEL_PAIRS key order; and the .nwb result equals the
+    .mat one, which equals the committed fixture."""
+    import json
+    import subprocess
+
+    r = subprocess.run([_H5_PY, "-c", _LOADER_SCRIPT, str(ROOT), str(REFERENCE)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["nwb_shape"] == [1000, 69] and d["mat_shape"] == [1000, 69] and d["h5_shape"] == [3600, 102]
+    assert d["nwb_names"] == d["rodent_pairs"] and d["nwb_names"][:5] == ["AnkleL", "AnkleR", "EarL", "EarR", "ElbowL"]
+    assert d["h5_names"] == d["mouse_pairs"] and d["h5_names"][:5] == ["Nose", "Ear_R", "Ear_L", "TTI", "Head"]
+    assert d["nwb_equals_mat"] and d["mat_equals_fixture"] and d["h5_equals_fixture"] and d["h5_finite"]
+    assert d["dtypes"] == ["float32", "float32"]
