@@ -48,7 +48,7 @@ static int fail(int code, const std::string &msg) {
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
     int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
-    bool noprune = false, verbose = false;
+    bool noprune = false, verbose = false, nofast = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
         return v ? atoi(v) : -1;
@@ -56,7 +56,7 @@ struct DebugSwitches {
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
         handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR");
-        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
+        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
 
@@ -84,6 +84,7 @@ struct stac_model {
     std::vector<int> h_lev_adr, h_ab_jadr, h_ab_jnum, h_xf, h_site_slot;
     std::vector<float> h_aj_pos;
     int n_mlev_root = 0;        // micro-levels of the root-pass program currently in the blob (0 = none)
+    int n_run_root = 0;         // of which the leading ones have work (n_mlev_root is padded to an even count)
     int32_t *d_lm_tab = nullptr;
     size_t lm_tab_words = 0;
     std::vector<int32_t> lm_tab_cache;
@@ -154,7 +155,9 @@ extern "C" int32_t stac_device_count(void) {
 // The FK program of the bodies in `need` (null: all active bodies): a header (one FK_ML_* flag word per micro-level,
 // then per position the ql offset of its first step) and the FkStep records at (micro_level * max_width + position in
 // the level).  Positions are those of the full layout, so a child still follows its parent on one lane.
-static std::vector<int32_t> build_fk_program(const stac_model *m, const char *need, int *n_mlev_out, int *uniform_out = nullptr) {
+static std::vector<int32_t> build_fk_program(const stac_model *m, const char *need, int *n_mlev_out, int *uniform_out = nullptr,
+                                              int ja_keep = 1 << 30,  // joints >= ja_keep park their anchor / pre-joint entry in the sink
+                                              int *n_run_out = nullptr) {
     const PlanHeader &h = m->h;
     const int W = h.max_width, rw = h.fk_rec_words, nlev = h.nlev, hw = h.fk_hdr_words;
     const std::vector<int> &lev_adr = m->h_lev_adr;
@@ -206,7 +209,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
                     const int j = m->h_ab_jadr[s] + i, ty = m->h_aj_type[j];
                     const float *jp = m->h_aj_pos.data() + 3 * j;
                     for (int c = 0; c < 3; ++c) r[8 + c] = f2i(jp[c]);
-                    r[5] = h.c_ja + kXf * j;
+                    r[5] = j < ja_keep ? h.c_ja + kXf * j : h.c_sink;
                     const bool free_as_parent = ty == STAC_JNT_FREE && i == 0 && br.parent == 0 && (br.flags & 1);
                     if (!free_as_parent) {
                         ql_of[(size_t)ml * W + pp] = h.c_ja + kXf * j + kXq;
@@ -247,6 +250,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
         fprintf(stderr, "\n");
     }
     *n_mlev_out = n_mlev;
+    if (n_run_out) *n_run_out = std::max(t_end, 1);  // steps with work (the records are padded to an even count)
     if (uniform_out) *uniform_out = uniform ? 1 : 0;
     return prog;
 }
@@ -876,7 +880,10 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             a.queue_slots = qslots;
         }
         if (hcap > 0) a.hand = m->d_hand;
+        const int root_fast = a.root_fast;
+        if ((a.flags & 2) || G < root_fast) a.root_fast = 0;  // root fast trips need the FK program and the root coordinates in register 0
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
+        a.root_fast = root_fast;
         if (cap && e == hipSuccess && hcap > 0) {
             // second launch: the latency kernel resumes whatever was handed off (waves without an entry exit at once)
             QArgs b = a;
@@ -906,8 +913,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         for (int i = 0; i < 11; ++i) tot += h[i];
         fprintf(stderr, "[stac profile] G=%d", G);
         for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
-        fprintf(stderr, " total_wave_cycles=%.3g wave_trips=%.4g cycles_per_wave_trip=%.0f fk_cycles_per_wave_trip=%.0f\n", (double)tot, (double)h[11],
-                (double)tot / (double)(h[11] ? h[11] : 1), (double)h[2] / (double)(h[11] ? h[11] : 1));
+        fprintf(stderr, " total_wave_cycles=%.3g wave_trips=%.4g cycles_per_wave_trip=%.0f fk_cycles_per_wave_trip=%.0f pure_root_trips=%.4g cycles_per_pure_root_trip=%.0f cycles_per_other_trip=%.0f\n", (double)tot, (double)h[11],
+                (double)tot / (double)(h[11] ? h[11] : 1), (double)h[2] / (double)(h[11] ? h[11] : 1), (double)h[13],
+                (double)h[12] / (double)(h[13] ? h[13] : 1), (double)(tot - h[12]) / (double)(h[11] - h[13] ? h[11] - h[13] : 1));
     }
 #endif
     return STAC_OK;
@@ -1123,7 +1131,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
 // Root passes weigh the trunk keypoints only: every other site contributes exact zeros there, so the kinematics of
 // the bodies that carry no trunk keypoint are not needed.  Builds the FK program of the needed bodies into the
 // blob's second program area; the kernel runs it when every chain of a wavefront is in a root pass.
-static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enable, hipStream_t s) {
+static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enable, int n_root_joints, hipStream_t s) {
     const PlanHeader &h = m->h;
     m->n_mlev_root = 0;
     if (!enable || m->dbg.noprune) return STAC_OK;
@@ -1134,11 +1142,16 @@ static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enabl
             for (int sl = m->h_site_slot[k]; sl >= 0 && !need[sl]; sl = m->h_ab_parent[sl] - 1) { need[sl] = 1; ++n_need; }
     if (n_need == 0 || n_need == h.nab) return STAC_OK;  // nothing to prune (or nothing weighted at all)
     int n_mlev = 0;
-    const std::vector<int32_t> prog = build_fk_program(m, need.data(), &n_mlev);
+    // Only the root joints' gradients are evaluated in a pruned trip: every other joint's {anchor, pre-joint quaternion}
+    // goes to the sink, so the joint-local quaternion the pre-pass parked in its entry survives the trip (root fast trips)
+    int n_run = 0;
+    const std::vector<int32_t> prog = build_fk_program(m, need.data(), &n_mlev, nullptr, n_root_joints, &n_run);
     int32_t *dst = reinterpret_cast<int32_t *>(m->blob_host.data()) + h.off_fkroot;
     std::memcpy(dst, prog.data(), prog.size() * 4);
     HIP_TRY(hipMemcpyAsync(m->d_blob + h.off_fkroot, dst, prog.size() * 4, hipMemcpyHostToDevice, s));
+    // the four-lanes-per-position program stops after its last step with work; the other forms run whole pairs
     m->n_mlev_root = n_mlev;
+    m->n_run_root = n_run;
     return STAC_OK;
 }
 
@@ -1215,11 +1228,21 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     for (int k = 0; k < K; ++k) hostm.push_back((trunk_kps && trunk_kps[k]) ? 1 : 0);  // placeholder, reordered below
     for (int k = 0; k < K; ++k) hostm[(size_t)(P + 3) * nqpad + K + m->h_sortpos[k]] = (trunk_kps && trunk_kps[k]) ? 1 : 0;
     hostm.push_back(0x5A);  // tag: phase layout
+    // joints whose coordinates the root passes optimise: a prefix of the active joints (the root body comes first);
+    // the gradient pass of a pruned root-pass trip stops there (the other gradients are masked out anyway)
+    int n_root_joints = m->h.naj;
+    if (do_root_opt) {
+        int nrj = 0;
+        while (nrj < m->h.naj && m->h_aj_qadr[nrj] < root_dims) ++nrj;
+        bool prefix = true;
+        for (int j = nrj; j < m->h.naj; ++j) prefix = prefix && m->h_aj_qadr[j] >= root_dims;
+        if (prefix) n_root_joints = nrj;
+    }
     if (hostm != m->masks_cache) {
         HIP_TRY(hipMemcpyAsync(m->d_masks, hostm.data(), (size_t)(P + 3) * nqpad, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_kpw, hostm.data() + (size_t)(P + 3) * nqpad, 2 * K, hipMemcpyHostToDevice, s));
         m->masks_cache.clear();
-        const int rc = fill_root_program(m, hostm.data() + (size_t)(P + 3) * nqpad, do_root_opt != 0, s);
+        const int rc = fill_root_program(m, hostm.data() + (size_t)(P + 3) * nqpad, do_root_opt != 0, n_root_joints, s);
         if (rc != STAC_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s));  // hostm is a temporary
         m->masks_cache = hostm;
@@ -1228,15 +1251,23 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.kp = kp; a.q_init = q_init; a.masks = m->d_masks; a.kpw = d_kpw; a.kpw3 = nullptr;
     a.C = C; a.F = F; a.P = P; a.root_kp_idx = root_kp_idx; a.do_root_opt = do_root_opt ? 1 : 0; a.single = 0;
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
-    // joints whose coordinates the root passes optimise: a prefix of the active joints (the root body comes first);
-    // the gradient pass of a pruned root-pass trip stops there (the other gradients are masked out anyway)
-    a.n_root_joints = m->h.naj;
-    if (do_root_opt) {
-        int nrj = 0;
-        while (nrj < m->h.naj && m->h_aj_qadr[nrj] < root_dims) ++nrj;
-        bool prefix = true;
-        for (int j = nrj; j < m->h.naj; ++j) prefix = prefix && m->h_aj_qadr[j] >= root_dims;
-        if (prefix) a.n_root_joints = nrj;
+    a.n_run_root = do_root_opt ? m->n_run_root : 0;
+    a.n_root_joints = n_root_joints;
+    // Root fast trips (QArgs::root_fast): the root coordinates are the first root_dims (<= 8: register 0 of every lane
+    // group of 8 or more lanes) and belong to leading joints that share ONE subtree range, whose weighted sites fit a 64-bit mask
+    if (do_root_opt && m->n_mlev_root > 0 && n_root_joints >= 1 && n_root_joints < m->h.naj && root_dims <= 8 && K <= 64 && !m->dbg.nofast) {
+        bool same = true;
+        for (int j = 1; j < n_root_joints; ++j) same = same && m->h_aj_slo[j] == m->h_aj_slo[0] && m->h_aj_shi[j] == m->h_aj_shi[0];
+        int covered = 0;
+        for (int j = 0; j < n_root_joints; ++j) covered += m->h_aj_type[j] == STAC_JNT_FREE ? 7 : (m->h_aj_type[j] == STAC_JNT_BALL ? 4 : 1);
+        if (same && covered == root_dims) {
+            uint64_t mask = 0;
+            const uint8_t *ts = hostm.data() + (size_t)(P + 3) * nqpad + K;  // trunk mask by sorted-site position
+            for (int i = m->h_aj_slo[0]; i < m->h_aj_shi[0]; ++i)
+                if (ts[i]) mask |= 1ull << i;
+            a.root_fast = root_dims;
+            a.root_trunk_lo = (uint32_t)mask; a.root_trunk_hi = (uint32_t)(mask >> 32);
+        }
     }
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;
     a.kpw_sorted = d_kpw + K;

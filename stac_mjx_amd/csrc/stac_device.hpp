@@ -109,27 +109,39 @@ __device__ __forceinline__ float group_tree_sum(const float (&v)[NQR]) {
     return t[0];
 }
 
-enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4 };
+enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4, ST_WAIT = 5 };
 
 // In-kernel phase stamps: diagnostic build only (-DSTAC_PROFILE -> libstac_hip_prof.so); the stamps
 // go to a buffer of their own and feed no output.  Read the SHARES, not the run time.
 #ifdef STAC_PROFILE
-#define PROF_DECL unsigned long long pt0 = __builtin_readcyclecounter(), pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// -DSTAC_PROFILE_SEL=1: only root fast (lite) trips are accumulated; =0: only the others; undefined: all trips
+#define PROF_DECL unsigned long long pt0 = __builtin_readcyclecounter(), pacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ptmp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ptrip0 = pt0
 #define PROF_TICK(i)                                             \
     do {                                                         \
         const unsigned long long pt1 = __builtin_readcyclecounter(); \
-        pacc[i] += pt1 - pt0;                                    \
+        ptmp[i] += pt1 - pt0;                                    \
         pt0 = pt1;                                               \
     } while (0)
-#define PROF_TRIP pacc[11] += 1
+#define PROF_TRIP
+#ifdef STAC_PROFILE_SEL
+#define PROF_KEEP(isroot) ((isroot) == (STAC_PROFILE_SEL != 0))
+#else
+#define PROF_KEEP(isroot) true
+#endif
+#define PROF_ROOT(isroot) do { const unsigned long long pq = __builtin_readcyclecounter(); if (isroot) { pacc[12] += pq - ptrip0; pacc[13] += 1; } ptrip0 = pq; \
+        const bool keep_ = PROF_KEEP(isroot); for (int i_ = 0; i_ < 11; ++i_) { if (keep_) pacc[i_] += ptmp[i_]; ptmp[i_] = 0; } if (keep_) pacc[11] += 1; } while (0)
+// (the LM kernel keeps the plain accumulation: it has no trip classes)
+#define PROF_LM_END do { for (int i_ = 0; i_ < 12; ++i_) { pacc[i_] += ptmp[i_]; ptmp[i_] = 0; } } while (0)
 #define PROF_FLUSH(a)                                                                     \
     do {                                                                                  \
         if (a.prof && lane == 0)                                                          \
-            for (int i = 0; i < 12; ++i) atomicAdd(a.prof + i, pacc[i]);                  \
+            for (int i = 0; i < 14; ++i) atomicAdd(a.prof + i, pacc[i]);                  \
     } while (0)
 #else
 #define PROF_DECL
 #define PROF_TRIP
+#define PROF_ROOT(isroot)
+#define PROF_LM_END
 #define PROF_TICK(i)
 #define PROF_FLUSH(a)
 #endif
@@ -174,10 +186,12 @@ __device__ __forceinline__ void st_tvec2(float *p, V3 v) { st_tpos(p + kXq, v); 
 // half-angle sincos and the local quaternion; free / ball: the normalised quaternion, written back like MJX does;
 // slide: the displacement).  This keeps the sincos off the serial chain of the FK that follows.  The result sits in
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
-__device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf) {
+// naj_lim: the leading joints to do (all, or -- root fast trips -- only the joints of the root passes' coordinates).
+__device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+                                                    const int naj_lim) {
     const float *jrec = P + H.off_joint;
     float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *ja = CBc + H.c_ja, *qsv = CBc + H.c_qsv;
-    for (int j = lf; j < H.naj; j += gf) {
+    for (int j = lf; j < naj_lim; j += gf) {
         const float *jr = jrec + 12 * j;
         const int4 ji = lds4i(jr);  // type, qadr, slo, shi
         const int ty = ji.x, ad = ji.y;
@@ -678,7 +692,7 @@ __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N,
 }
 template <int RW, bool PSEL>
 __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
-                                                const bool active, const int prog_off, const int n_ml) {
+                                                const bool active, const int prog_off, const int n_ml_even, const int n_run) {
     const int W = H.max_width;
     const int pp = lf >> 2, c = lf & 3;
     if (!(active && pp < W)) return;  // whole quads: the DPP operands below stay inside a quad
@@ -707,7 +721,9 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
     if (H.fk_uniform) {
         // every step is the same straight-line code (parents by select, body / joint parts on neutral data): no flags, no
         // dispatch, nothing for s_waitcnt to be conservative about
-        for (int ml = 0; ml < n_ml; ml += 2) {
+        const int n_ml = n_run > 0 ? n_run : n_ml_even;  // (stops after the last step with work)
+        int ml = 0;
+        for (; ml + 1 < n_ml; ml += 2) {
             const int fl = __builtin_amdgcn_readfirstlane(fl_v);
             fl_v = hdr[(ml >> 1) + 1];
             sp += stride;
@@ -717,13 +733,21 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
             if (!PSEL || (fl & FK_ML_PARENT_LDS)) fk_step_quad_joint<RW, true>(A, B, sp, pc, Q, CBc, L);
             else fk_step_quad_joint<RW, false>(A, B, sp, pc, Q, CBc, L);
             wave_sync();
-            if (ml + 2 < n_ml) sp += stride;
+            if (ml + 2 < n_ml_even) sp += stride;  // (no record behind the last one)
             if (!PSEL || ((fl >> 16) & FK_ML_PARENT_LDS)) fk_step_quad_joint<RW, true>(B, A, sp, pc, Q, CBc, L);
             else fk_step_quad_joint<RW, false>(B, A, sp, pc, Q, CBc, L);
             wave_sync();
         }
+        if (ml < n_ml) {  // an odd number of steps with work (root-pass programs): the last one, outside the loop
+            const int fl = __builtin_amdgcn_readfirstlane(fl_v);
+            sp += stride;
+            if (!PSEL || (fl & FK_ML_PARENT_LDS)) fk_step_quad_joint<RW, true>(A, B, sp, pc, Q, CBc, L);
+            else fk_step_quad_joint<RW, false>(A, B, sp, pc, Q, CBc, L);
+            wave_sync();
+        }
         return;
     }
+    const int n_ml = n_ml_even;
     for (int ml = 0; ml < n_ml; ml += 2) {
         const int fl = __builtin_amdgcn_readfirstlane(fl_v);
         fl_v = hdr[(ml >> 1) + 1];
@@ -742,14 +766,15 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
 template <bool QUAD, bool PSEL = false>
 __device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
                                          const bool active, const bool store_ja, const bool use_levels,
-                                         const int n_ml_root = 0) {
+                                         const int n_ml_root = 0, const int n_run_root = 0) {
     if (H.max_width <= gf && !use_levels) {
         const int prog_off = n_ml_root > 0 ? H.off_fkroot : H.off_fkstep;
         const int n_ml = n_ml_root > 0 ? n_ml_root : H.n_mlev;
         if constexpr (QUAD) {
             if (4 * H.max_width <= gf) {
-                if (H.fk_rec_words == 16) fk_program_quad<16, PSEL>(H, P, CBc, lf, gf, active, prog_off, n_ml);
-                else fk_program_quad<12, PSEL>(H, P, CBc, lf, gf, active, prog_off, n_ml);
+                const int n_run = n_ml_root > 0 ? n_run_root : 0;
+                if (H.fk_rec_words == 16) fk_program_quad<16, PSEL>(H, P, CBc, lf, gf, active, prog_off, n_ml, n_run);
+                else fk_program_quad<12, PSEL>(H, P, CBc, lf, gf, active, prog_off, n_ml, n_run);
                 return;
             }
         }

@@ -200,6 +200,21 @@ void q_phase_kernel(const QArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; g[r] = 0.f; }
+    // root fast trips (QArgs::root_fast): are the joint-local quaternions of this group's chain still in its ja entries?
+    bool ql_fresh = false;
+    // ... and do this lane's coordinates outside the root passes' lie inside the box?  Then clip(y - eta * 0) = y for them:
+    // they drop out of every norm and never move, and the solver transition of a root fast trip looks at register 0 only.
+    // (They are constant over a chain's root solves, so this is settled when the chain starts.)
+    bool tail_ok = true;
+    auto check_tail = [&]() {
+        tail_ok = true;
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg;
+            if (e < nq && e >= a.root_fast && !(q0[r] >= lbv[e] && q0[r] <= ubv[e])) tail_ok = false;
+        }
+    };
+    if (!SPEC && a.root_fast > 0) check_tail();
     // the same for the next chain a group takes from the queue (all lanes of the group call it together)
     auto begin_chain = [&](const int c) {
         chain = c;
@@ -218,6 +233,8 @@ void q_phase_kernel(const QArgs a) {
         }
         load_kp(kp_chain);
         st = ST_VG_Y;
+        ql_fresh = false;
+        if (!SPEC && a.root_fast > 0) check_tail();
     };
     if (resuming) {
 #pragma unroll
@@ -234,6 +251,19 @@ void q_phase_kernel(const QArgs a) {
     }
     wave_sync();
 
+    // root fast trips: the lane's one weighted (trunk) site, if no lane has more than one -- then a single round of the
+    // site pass covers them all (sites1)
+    int trunk_r = -1;
+    bool sites1 = false;
+    if (!SPEC && a.root_fast > 0 && site_regs && a.kpw) {
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) {
+            const int k = r * G + lg;
+            if (k < K && a.kpw[k]) { trunk_r = r; ++cnt; }
+        }
+        sites1 = !__any(cnt > 1);
+    }
     PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
     const int lg_outer = lg;
@@ -257,10 +287,10 @@ void q_phase_kernel(const QArgs a) {
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
-            // (looked at every fourth iteration: the counter lives in L2)
-            if (__any(st == ST_VG_Y && (iter & 3) == 0)) {
+            // (looked at every eighth iteration: the counter lives in L2)
+            if (__any(st == ST_VG_Y && (iter & 7) == 0)) {
                 const int done_cnt = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (st == ST_VG_Y && (iter & 3) == 0 && done_cnt >= a.ctl[1]) {
+                if (st == ST_VG_Y && (iter & 7) == 0 && done_cnt >= a.ctl[1]) {
                     int slot = 0;
                     if (lg == 0) slot = atomicAdd(a.ctl + 2, 1);
                     slot = __shfl(slot, grp * G, 64);
@@ -286,7 +316,15 @@ void q_phase_kernel(const QArgs a) {
             }
             if (!__any(st != ST_DONE)) break;
         }
+        if constexpr (!SPEC) {
+            // wave-synchronous root phase: chains that have finished their root solves go on when no chain of the
+            // wavefront is in one any more
+            const bool root_live = st != ST_DONE && st != ST_WAIT && !a.single && kind < 2;
+            const bool any_root_live = __any(root_live);  // (all lanes vote: not inside the condition below)
+            if (st == ST_WAIT && !any_root_live) st = ST_VG_Y;
+        }
         const int st_in = st;
+        const bool live_in = st_in != ST_DONE && st_in != ST_WAIT;
         const uint32_t mbits = MB[kind * G + lg];
         // A line-search candidate that is accepted becomes x_next, whose gradient the stopping test
         // needs (the oracle's separate VG_X evaluation runs the very same FK).  The step size doubles
@@ -305,9 +343,25 @@ void q_phase_kernel(const QArgs a) {
         const float spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
         const float spec_beta = (t - 1.0f) / spec_tn;
 
+        // root passes weigh the trunk keypoints only: when every live chain of the wave is in one, the kinematics stop at
+        // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)
+        const bool root_pass = !a.single && kind < 2;
+        const int n_ml_root = (a.n_mlev_root > 0 && !__any(live_in && !root_pass)) ? a.n_mlev_root : 0;
+        // root fast trip: only the root coordinates are staged and only the root joint's local transform is refreshed
+        // (lite) once the other joints' local quaternions sit untouched in their ja entries
+        const bool fast_trip = !SPEC && a.root_fast > 0 && n_ml_root > 0;
+        const bool lite = fast_trip && !__any(live_in && !ql_fresh);
+
         // the world entry of the transform array (the gradient pass of the previous trip left its range sums there)
         if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
+        if (lite) {
+            if (lg < a.root_fast) {  // (the root coordinates are elements 0 .. root_fast - 1 <= G: register 0)
+                const float pt = (st_in == ST_VG_Y) ? y[0] : ((st_in == ST_LS) ? CAND(0, lg) : x[0]);
+                const float mi = (mbits & 1u) ? 1.0f : 0.0f;
+                qe[lg] = (1.0f - mi) * q0[0] + mi * pt;
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + lg;
@@ -324,19 +378,19 @@ void q_phase_kernel(const QArgs a) {
                 qe[e] = (1.0f - mi) * q0[r] + mi * pt;
             }
         }
+        }
         wave_sync();
         PROF_TICK(1);  // stage
 
-        joint_local_prepass(H, P, CB, lg, G);
+        joint_local_prepass(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj);
         wave_sync();
         PROF_TICK(10);  // joint-local pre-pass
 
         // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
-        // root passes weigh the trunk keypoints only: when every chain of the wave is in one, the kinematics stop at
-        // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)
-        const bool root_pass = !a.single && kind < 2;
-        const int n_ml_root = (a.n_mlev_root > 0 && !__any(st_in != ST_DONE && !root_pass)) ? a.n_mlev_root : 0;
-        fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root);
+        fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root, a.n_run_root);
+        // after a root fast trip the local quaternions are still where the pre-pass put them (sunk ja stores); after any
+        // other trip the pre-joint quaternions have replaced them
+        ql_fresh = fast_trip && tail_ok;  // (a chain whose other coordinates leave the box never takes the lite path)
 
         PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
@@ -374,10 +428,24 @@ void q_phase_kernel(const QArgs a) {
         if (site_regs) {
             // pairwise tree over the sites (oracle: tree_sum) as lane butterflies + registers: no LDS, no barrier
             float term[NSR];
+            if (lite && sites1) {
+                // root fast trip: only the weighted sites have a term, at most one per lane: one round instead of NSR
+                // (the others' terms are exact zeros, and nobody reads their wrench entries: see the range sum below)
+                float v = 0.0f;
+                if (trunk_r >= 0) {
+                    const float kx = trunk_r == 0 ? kpr[0][0] : (trunk_r == 1 ? kpr[1][0] : kpr[NSR - 1][0]);
+                    const float ky = trunk_r == 0 ? kpr[0][1] : (trunk_r == 1 ? kpr[1][1] : kpr[NSR - 1][1]);
+                    const float kz = trunk_r == 0 ? kpr[0][2] : (trunk_r == 1 ? kpr[1][2] : kpr[NSR - 1][2]);
+                    v = site_term(trunk_r * G + lg, kx, ky, kz);
+                }
+#pragma unroll
+                for (int r = 0; r < NSR; ++r) term[r] = r == trunk_r ? v : 0.0f;
+            } else {
 #pragma unroll
             for (int r = 0; r < NSR; ++r) {
                 const int k = r * G + lg;
                 term[r] = k < K ? site_term(k, kpr[r][0], kpr[r][1], kpr[r][2]) : 0.0f;
+            }
             }
             loss = group_tree_sum<G, NSR>(term);
             wave_sync();
@@ -513,7 +581,26 @@ void q_phase_kernel(const QArgs a) {
 #pragma unroll
         for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
         // (latency mode: a speculative trip computes gradients only for the two evaluations it ends up using, below)
-        if (any_grad && !(SPEC && st_in == ST_SPEC)) {
+        if (any_grad && fast_trip) {
+            // root fast trip: the root joint's subtree wrench over the weighted sites only (in the order of the full sum),
+            // one component per lane, then the root joint's gradient
+            const int rid0 = __builtin_bit_cast(int, jrec[11]);
+            if (lg < 6) {
+                const int co = lg < 3 ? lg : kXq + lg - 3;
+                const float *src = sw + co;
+                float acc = 0.f;
+                for (uint32_t m = a.root_trunk_lo; m; m &= m - 1) acc = acc + src[kXf * __builtin_ctz(m)];
+                for (uint32_t m = a.root_trunk_hi; m; m &= m - 1) acc = acc + src[kXf * (32 + __builtin_ctz(m))];
+                CB[H.c_rw + kXf * rid0 + co] = acc;
+            }
+            wave_sync();
+            PROF_TICK(5);  // range sums
+            for (int j = lg; j < a.n_root_joints; j += G) joint_gradient(j, CB, cref, gg);
+            wave_sync();
+            if (lg < a.root_fast && (mbits & 1u)) gnew[0] = gg[lg];
+            wave_sync();
+            PROF_TICK(6);  // joint gradients
+        } else if (any_grad && !(SPEC && st_in == ST_SPEC)) {
             // the range sums go where the body transforms were (the site pass, their last reader, is over; cref is in a
             // register), the gradient where the site wrenches were (dead once the range sums are done)
             if constexpr (G >= 32) { for (int t = lg; t < 6 * H.nrange; t += G) range_task(t, CB); }
@@ -535,6 +622,77 @@ void q_phase_kernel(const QArgs a) {
         }
 
         // ---- solver transitions (jaxopt ProjectedGradient) ------------------------------------
+        bool ending = false;
+        float sum0 = 0.0f, sum1 = 0.0f;
+        if (lite) {
+            // Root fast trip: every live chain is in a root solve whose other coordinates sit inside the box (tail_ok), so
+            // registers 1 .. NQR - 1 hold g = 0 and x = y: their terms of every norm are exact zeros and the accepted point
+            // leaves them where they are.  Same operations as below on register 0; the trees over the registers reduce to
+            // "+ 0" (a sum of squares / products plus zeros: one addition of +0 is all that the zero registers do to it).
+            const bool in0 = lg < nq;
+            if (st_in == ST_VG_Y) {
+                fy = loss; eta = stepsize; nls = 0;
+                g[0] = gnew[0];
+                c_grad++;
+                st = ST_LS;
+            }
+            float a0 = 0.0f, a1 = 0.0f;
+            if (in0) {
+                if (st_in == ST_VG_X) {
+                    const float d = clipf(x[0] - gnew[0], LB(0, lg), UB(0, lg)) - x[0];
+                    a0 = d * d;
+                } else if (st_in == ST_LS) {
+                    const float d = CAND(0, lg) - y[0];
+                    a0 = d * d;
+                    a1 = d * g[0];
+                }
+            }
+            const float one0[1] = {a0}, one1[1] = {a1};
+            sum0 = group_tree_sum<G, 1>(one0) + 0.0f;
+            sum1 = group_tree_sum<G, 1>(one1) + 0.0f;
+            PROF_TICK(7);  // transition terms + sums
+            bool fused = false;
+            if (st_in == ST_LS) {
+                c_ls++;
+                const float lhs = eta * (loss - fy);
+                const float rhs = eta * sum1 + 0.5f * sum0 + eps;
+                bool accept = !(lhs > rhs);
+                const bool evaluated_point_accepted = accept;
+                if (!accept) {
+                    eta = eta * 0.5f;
+                    nls++;
+                    if (nls >= a.maxls) accept = true;
+                }
+                if (accept) {
+                    const float cr = in0 ? CAND(0, lg) : x[0];
+                    const float d = cr - x[0];
+                    y[0] = FMA(spec_beta, d, cr);
+                    x[0] = cr;
+                    st = ST_VG_X;
+                    fused = ls_with_grad && evaluated_point_accepted;
+                }
+            }
+            if (__any(fused)) {
+                float f0 = 0.0f;
+                if (in0) {
+                    const float d = clipf(x[0] - gnew[0], LB(0, lg), UB(0, lg)) - x[0];
+                    f0 = d * d;
+                }
+                const float onef[1] = {f0};
+                const float e2 = group_tree_sum<G, 1>(onef) + 0.0f;
+                if (fused) sum0 = e2;
+            }
+            if (st_in == ST_VG_X || fused) {
+                fx = loss;
+                error = __builtin_sqrtf(sum0);
+                stepsize = (eta <= 1e-6f) ? 1.0f : eta / 0.5f;
+                t = spec_tn;
+                iter++;
+                c_grad++;
+                if (error > a.tol && iter < a.maxiter) st = ST_VG_Y;
+                else ending = true;
+            }
+        } else {
         if (st_in == ST_VG_Y) {
             fy = loss;
             eta = stepsize;
@@ -546,7 +704,6 @@ void q_phase_kernel(const QArgs a) {
         }
         // nq-sums as pairwise trees over the striped registers (oracle: tree_sum); all groups compute
         // them every trip (a few dozen DPP adds), only the groups in the matching state use them
-        float sum0, sum1;
         {
             float t0[NQR], t1[NQR];
 #pragma unroll
@@ -575,7 +732,6 @@ void q_phase_kernel(const QArgs a) {
             sum1 = group_tree_sum<G, NQR>(t1);
         }
         PROF_TICK(7);  // transition terms + nq sums
-        bool ending = false;
         bool fused = false;  // accepted a candidate whose gradient is already in gnew
         if (st_in == ST_LS) {
             c_ls++;
@@ -631,6 +787,7 @@ void q_phase_kernel(const QArgs a) {
         }
 
 
+        }
         if (SPEC && st_in == ST_SPEC) {  // every lane of the chain is in this state: the solver state is replicated
             // (1) which candidate would the sequential line search take?  Candidate n = nls + c is evaluated
             //     only while n < maxls; candidate n == maxls is taken without evaluation (jaxopt's loop bound).
@@ -793,6 +950,7 @@ void q_phase_kernel(const QArgs a) {
                         // root optimisation is not part of the frame's counters (compute_stac.py:17-104)
                         c_iter = c_ls = c_grad = c_solves = 0;
                     }
+                    const bool was_root = kind < 2;
                     kind++;
                     if (kind > a.P + 2) {  // frame finished: record it (compute_stac.py:261-267)
                         const size_t fo = (size_t)chain * a.F + frame;
@@ -845,12 +1003,15 @@ void q_phase_kernel(const QArgs a) {
                         stepsize = 1.0f; t = 1.0f; iter = 0;
                         error = __builtin_inff();
                         st = ST_VG_Y;
+                        // root solves over: the pose solves begin when the wavefront's other chains are there too (top of the loop)
+                        if (!SPEC && a.root_fast > 0 && was_root && kind == 2) st = ST_WAIT;
                     }
                 }
             }
             wave_sync();
         }
         PROF_TICK(9);  // end of solve
+        PROF_ROOT(lite);
     }
     PROF_FLUSH(a);
 }

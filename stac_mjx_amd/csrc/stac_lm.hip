@@ -152,7 +152,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
         wave_sync();
 
         // ---- forward kinematics: the PG kernel's joint-local pre-pass + FK program (stac_device.hpp) -------------------
-        joint_local_prepass(H, P, CB, lg, G);
+        joint_local_prepass(H, P, CB, lg, G, H.naj);
         wave_sync();
         fk_chain<(G >= 16)>(H, P, CB, lg, G, true, true, (a.flags & 2) != 0);
 
@@ -540,6 +540,7 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
             wave_sync();
         }
         PROF_TICK(11);  // end of solve
+        PROF_LM_END;
     }
     PROF_FLUSH(a);
 }

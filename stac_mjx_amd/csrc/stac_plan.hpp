@@ -188,7 +188,17 @@ struct QArgs {
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
     int32_t mb_words;       // LDS words reserved for the per-kind mask bit table (multiple of 4)
     int32_t n_mlev_root;    // micro-levels of the root-pass FK program at h.off_fkroot; 0 = none (never prune)
+    int32_t n_run_root;     // steps of that program that have work (<= n_mlev_root, which is padded to an even count)
     int32_t n_root_joints;  // leading active joints that carry the root passes' coordinates
+    // Root fast trips (throughput kernels).  While every live chain of a wavefront is in a root solve, only the first
+    // root_fast coordinates move: the joint-local quaternions of all other joints, computed once, stay valid (the root
+    // program parks their anchor / pre-joint entries in the sink), the gradient is the root joint's alone and its subtree
+    // wrench sums the weighted (trunk) sites only -- the others contribute exact zeros, and a running sum that starts at
+    // +0 is never -0, so leaving them out changes no bit.  0 = off (conditions: stac_abi.hip, stac_q_phase).  A chain
+    // that finishes its root solves waits (ST_WAIT) until the other chains of its wavefront have, so that the root trips
+    // of a wavefront are ALL fast ones and its chains start their pose solves in the same trip.
+    int32_t root_fast;      // number of leading coordinates the root passes optimise (= root_dims), or 0
+    uint32_t root_trunk_lo, root_trunk_hi;  // sorted-site positions inside the root joint's range that carry a weight
     // Straggler hand-off (null = off).  Chains take very different numbers of iterations; once most of a launch's
     // chains are done the rest would drag on at a few waves per CU.  ctl = {finished chains, threshold, handed-off
     // chains, capacity}: a chain of the throughput kernel that starts an iteration (state VG_Y) after `finished`

@@ -153,10 +153,12 @@ def test_config4_one_gpu_share_125k_frames(rodent_setup, rodent_cfg):
     ms = res["marker_sites"].cpu().numpy()
     assert marker_error_mm(ms, kp) < 2.0  # 1 mm keypoint noise
     assert (res["frame_error"].cpu().numpy() > 0).all() and (res["counters"][..., 3].cpu().numpy() == 6).all()
-    # recorded markers are FK(recorded qpos), bit for bit, on a strided sample of all 125 000 poses
+    # recorded markers are FK(recorded qpos) on a strided sample of all 125 000 poses (the public stac_fk normalises the
+    # stored unit quaternion once more, which may move the last bit: 1e-6 m, not tolerance 0; the sampled clips below
+    # are compared with the oracle bit for bit)
     flat_q = res["qpos"].reshape(-1, 74)[::997]
     again = eng.fk(flat_q, want=("site_xpos",))["site_xpos"]
-    assert torch.equal(again, res["marker_sites"].reshape(-1, 23, 3)[::997])
+    assert torch.allclose(again, res["marker_sites"].reshape(-1, 23, 3)[::997], rtol=0, atol=1e-6)
     orc = _oracle(fs, tol=tol, maxiter=maxiter)
     orc.set_site_pos(off)
     sel = [0, 251, 499]
@@ -213,7 +215,7 @@ def test_mouse_real_recording_full_solves(mouse_setup):
     # the un-jittered first 200 clips are the real frames: those that were also in the 8 x 2 sample start identically
     np.testing.assert_array_equal(q[0, 0], ref["qpos"][0, 0])
     again = eng.fk(res["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
-    assert torch.equal(again, res["marker_sites"].reshape(-1, fs.tables.nsite, 3))
+    assert torch.allclose(again, res["marker_sites"].reshape(-1, fs.tables.nsite, 3), rtol=0, atol=1e-6)  # see config 4
     # the fit reduces the marker error of the root-only pose by a wide margin on every frame
     e_fit = np.linalg.norm(res["marker_sites"].cpu().numpy() - big.reshape(2000, 1, 34, 3), axis=-1).mean(axis=(1, 2))
     assert np.median(e_fit) < 0.03, np.median(e_fit)  # the oracle reaches 0.017 on the sampled real frames
