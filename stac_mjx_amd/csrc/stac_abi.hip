@@ -1253,6 +1253,7 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
     a.n_run_root = do_root_opt ? m->n_run_root : 0;
     a.n_root_joints = n_root_joints;
+    a.root_free = -1;
     // Root fast trips (QArgs::root_fast): the root coordinates are the first root_dims (<= 8: register 0 of every lane
     // group of 8 or more lanes) and belong to leading joints that share ONE subtree range, whose weighted sites fit a 64-bit mask
     if (do_root_opt && m->n_mlev_root > 0 && n_root_joints >= 1 && n_root_joints < m->h.naj && root_dims <= 8 && K <= 64 && !m->dbg.nofast) {
@@ -1267,6 +1268,9 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
                 if (ts[i]) mask |= 1ull << i;
             a.root_fast = root_dims;
             a.root_trunk_lo = (uint32_t)mask; a.root_trunk_hi = (uint32_t)(mask >> 32);
+            if (n_root_joints == 1 && m->h_aj_type[0] == STAC_JNT_FREE && m->h_aj_qadr[0] == 0 && root_dims == 7) {
+                a.root_free = 0;  // active joint 0 is the first quaternion joint: ordinal 0 (JointRec::q0, build_plan)
+            }
         }
     }
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;

@@ -283,7 +283,6 @@ void q_phase_kernel(const QArgs a) {
         float *const bx = CB + H.c_bx, *const ja = CB + H.c_ja, *const jn = CB + H.c_jn, *const qsv = CB + H.c_qsv;
         float *const sw = CB + H.c_sw, *const gg = CB + H.c_gg, *const r2 = CB + H.c_r2;
         float *const qe = CB + H.c_qe, *const kpl = CB + H.c_kp;
-        (void)jn; (void)qsv; (void)ja;
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
@@ -355,35 +354,70 @@ void q_phase_kernel(const QArgs a) {
         // the world entry of the transform array (the gradient pass of the previous trip left its range sums there)
         if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
-        if (lite) {
+        bool prepass_done = false;
+        if (lite && a.root_free >= 0) {
+            // The root passes' coordinates are ONE free joint at qpos 0 .. 6 (QArgs::root_free = its quaternion ordinal):
+            // staging and its pre-pass in one go, out of the registers of lanes 0 .. 6.  Every lane fetches the four raw
+            // quaternion components from lanes 3 .. 6 (one cross-lane round trip) and computes |q| itself -- the same fma
+            // chain as normalize4 -- so the four components are divided side by side and stored by their own lanes:
+            // {position, unit quaternion} into the joint's entry (the FK program's synthetic parent of the root body),
+            // the unit quaternion and |q| for the gradient pass, and the evaluation point as MJX writes it back.
+            const float pt = (st_in == ST_VG_Y) ? y[0] : ((st_in == ST_LS) ? CAND(0, lg) : x[0]);
+            const float mi = (mbits & 1u) ? 1.0f : 0.0f;
+            const float v = (1.0f - mi) * q0[0] + mi * pt;
+            const int gb = grp * G;
+            const float qw = __shfl(v, gb + 3, 64), qx = __shfl(v, gb + 4, 64), qy = __shfl(v, gb + 5, 64), qz = __shfl(v, gb + 6, 64);
+            const float n = __builtin_sqrtf(FMA(qz, qz, FMA(qy, qy, FMA(qx, qx, qw * qw))));
+            const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
+            float *ja0 = ja;  // active joint 0
+            if (lg < 3) {
+                qe[lg] = v;
+                ja0[lg] = v;
+            } else if (lg < 7) {
+                const float qn = v / dn;
+                const int c = lg - 3;  // 0 .. 3 = w, x, y, z
+                qe[lg] = qn;
+                ja0[kXq + (c == 0 ? 3 : c - 1)] = qn;  // entries hold (x, y, z, w)
+                qsv[4 * a.root_free + c] = qn;
+                if (c == 0) jn[a.root_free] = n;
+            }
+            prepass_done = true;
+        } else if (lite) {
             if (lg < a.root_fast) {  // (the root coordinates are elements 0 .. root_fast - 1 <= G: register 0)
                 const float pt = (st_in == ST_VG_Y) ? y[0] : ((st_in == ST_LS) ? CAND(0, lg) : x[0]);
                 const float mi = (mbits & 1u) ? 1.0f : 0.0f;
                 qe[lg] = (1.0f - mi) * q0[0] + mi * pt;
             }
         } else {
+        // straight-line: the bounds of all the lane's coordinates are fetched together (one LDS round trip, not one per
+        // coordinate behind a branch each), the point is chosen by selects
+        float lbs[NQR], ubs[NQR];
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg, eb = e < nq ? e : 0;
+            lbs[r] = LB(r, eb);
+            ubs[r] = UB(r, eb);
+        }
+        const float eta_s = (SPEC && st_in == ST_SPEC) ? eta * spec_pow : eta;  // eta / 2^c (exact)
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + lg;
-            if (e < nq) {
-                float pt;
-                if (SPEC && st_in == ST_SPEC) {
-                    const float ec = eta * spec_pow;  // eta / 2^c (exact)
-                    const float cr = clipf(FMA(-ec, g[r], y[r]), LB(r, e), UB(r, e));
-                    pt = role < NC ? cr : FMA(spec_beta, cr - x[r], cr);
-                } else {
-                    pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? CAND(r, e) : x[r]);
-                }
-                const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
-                qe[e] = (1.0f - mi) * q0[r] + mi * pt;
-            }
+            const float cr = clipf(FMA(-eta_s, g[r], y[r]), lbs[r], ubs[r]);
+            float pt;
+            if (SPEC && st_in == ST_SPEC) pt = role < NC ? cr : FMA(spec_beta, cr - x[r], cr);
+            else pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cr : x[r]);
+            const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
+            const float v = (1.0f - mi) * q0[r] + mi * pt;
+            if (e < nq) qe[e] = v;
         }
         }
         wave_sync();
         PROF_TICK(1);  // stage
 
-        joint_local_prepass(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj);
-        wave_sync();
+        if (!prepass_done) {
+            joint_local_prepass(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj);
+            wave_sync();
+        }
         PROF_TICK(10);  // joint-local pre-pass
 
         // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
@@ -577,6 +611,26 @@ void q_phase_kernel(const QArgs a) {
                     ggx[qa + 3] = (2.0f * FMA(qh.w, tl.z, -uxt.z)) / dn;
                 }
         };
+        // The gradient of a free joint at qpos 0 .. 6 (active joint 0; QArgs::root_free / free0p), component lg on lane lg
+        // < 7: the formulas of joint_gradient's free branch -- same operations, same order per component -- but the four
+        // divisions side by side instead of one lane doing all seven components while the others wait.
+        auto free0_gradient = [&](float *CBx, const V3 crefx, const int rid, const int qord) -> float {
+            const float *rw = CBx + H.c_rw + kXf * rid;
+            const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
+            const V3 anchor = ld_tpos(CBx + H.c_ja);
+            const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
+            const Q4 qh = ld4(CBx + H.c_qsv + 4 * qord);
+            const V3 u = {qh.x, qh.y, qh.z};
+            const V3 uxt = cross3(u, tau);
+            const float n = CBx[H.c_jn + qord];
+            const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
+            const float tl_i = lg == 4 ? tau.x : (lg == 5 ? tau.y : tau.z);
+            const float ux_i = lg == 4 ? uxt.x : (lg == 5 ? uxt.y : uxt.z);
+            const float num = lg == 3 ? -2.0f * dot3(tau, u) : 2.0f * FMA(qh.w, tl_i, -ux_i);
+            const float gq = num / dn;
+            const float gf = lg == 0 ? Fs.x : (lg == 1 ? Fs.y : Fs.z);
+            return lg < 3 ? gf : gq;
+        };
         float gnew[NQR];
 #pragma unroll
         for (int r = 0; r < NQR; ++r) gnew[r] = 0.f;
@@ -595,9 +649,14 @@ void q_phase_kernel(const QArgs a) {
             }
             wave_sync();
             PROF_TICK(5);  // range sums
-            for (int j = lg; j < a.n_root_joints; j += G) joint_gradient(j, CB, cref, gg);
-            wave_sync();
-            if (lg < a.root_fast && (mbits & 1u)) gnew[0] = gg[lg];
+            if (a.root_free >= 0) {
+                const float gv = free0_gradient(CB, cref, rid0, a.root_free);
+                if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
+            } else {
+                for (int j = lg; j < a.n_root_joints; j += G) joint_gradient(j, CB, cref, gg);
+                wave_sync();
+                if (lg < a.root_fast && (mbits & 1u)) gnew[0] = gg[lg];
+            }
             wave_sync();
             PROF_TICK(6);  // joint gradients
         } else if (any_grad && !(SPEC && st_in == ST_SPEC)) {
@@ -703,30 +762,28 @@ void q_phase_kernel(const QArgs a) {
             st = SPEC ? ST_SPEC : ST_LS;
         }
         // nq-sums as pairwise trees over the striped registers (oracle: tree_sum); all groups compute
-        // them every trip (a few dozen DPP adds), only the groups in the matching state use them
+        // them every trip (a few dozen DPP adds), only the groups in the matching state use them.  Straight-line: the
+        // bounds come in one LDS round trip for the whole transition, both candidates of a term are computed and one is selected.
+        float lbs[NQR], ubs[NQR];
+#pragma unroll
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + lg, eb = e < nq ? e : 0;
+            lbs[r] = LB(r, eb);
+            ubs[r] = UB(r, eb);
+        }
         {
+            const float eta_s = (SPEC && st_in == ST_SPEC) ? eta * spec_pow : eta;
+            const bool isx = st_in == ST_VG_X, isl = st_in == ST_LS || (SPEC && st_in == ST_SPEC);
             float t0[NQR], t1[NQR];
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
-                float a0 = 0.0f, a1 = 0.0f;
-                if (e < nq) {
-                    if (st_in == ST_VG_X) {
-                        const float d = clipf(x[r] - gnew[r], LB(r, e), UB(r, e)) - x[r];
-                        a0 = d * d;
-                    } else if (st_in == ST_LS) {
-                        const float d = CAND(r, e) - y[r];
-                        a0 = d * d;
-                        a1 = d * g[r];
-                    } else if (SPEC && st_in == ST_SPEC) {
-                        const float ec = eta * spec_pow;
-                        const float d = clipf(FMA(-ec, g[r], y[r]), LB(r, e), UB(r, e)) - y[r];
-                        a0 = d * d;
-                        a1 = d * g[r];
-                    }
-                }
-                t0[r] = a0;
-                t1[r] = a1;
+                const float dx = clipf(x[r] - gnew[r], lbs[r], ubs[r]) - x[r];
+                const float dl = clipf(FMA(-eta_s, g[r], y[r]), lbs[r], ubs[r]) - y[r];
+                const float d = isx ? dx : dl;
+                const bool on = e < nq && (isx || isl);
+                t0[r] = on ? d * d : 0.0f;
+                t1[r] = (on && isl) ? d * g[r] : 0.0f;
             }
             sum0 = group_tree_sum<G, NQR>(t0);
             sum1 = group_tree_sum<G, NQR>(t1);
@@ -749,7 +806,7 @@ void q_phase_kernel(const QArgs a) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
-                    const float cr = e < nq ? CAND(r, e) : x[r];
+                    const float cr = e < nq ? clipf(FMA(-eta, g[r], y[r]), lbs[r], ubs[r]) : x[r];
                     const float d = cr - x[r];
                     y[r] = FMA(beta, d, cr);
                     x[r] = cr;
@@ -765,12 +822,8 @@ void q_phase_kernel(const QArgs a) {
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
-                float a0 = 0.0f;
-                if (e < nq) {
-                    const float d = clipf(x[r] - gnew[r], LB(r, e), UB(r, e)) - x[r];
-                    a0 = d * d;
-                }
-                t0[r] = a0;
+                const float d = clipf(x[r] - gnew[r], lbs[r], ubs[r]) - x[r];
+                t0[r] = e < nq ? d * d : 0.0f;
             }
             const float e2 = group_tree_sum<G, NQR>(t0);
             if (fused) sum0 = e2;
