@@ -48,7 +48,7 @@ static int fail(int code, const std::string &msg) {
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
     int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
-    bool noprune = false, verbose = false, nofast = false;
+    bool noprune = false, verbose = false, nofast = false, nofree0 = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
         return v ? atoi(v) : -1;
@@ -56,7 +56,7 @@ struct DebugSwitches {
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
         handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR");
-        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
+        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
 
@@ -757,6 +757,12 @@ static int pick_lanes(const stac_model *m, int requested, int nchains, int nkind
     return 64;
 }
 
+// QArgs::free0p for a launch with G lanes per group: active joint 0 a free joint at qpos 0 .. 6 (the first quaternion
+// joint: ordinal 0, JointRec::q0 in build_plan) and its seven coordinates in register 0 of lanes 0 .. 6
+static int free0_ordinal_p1(const stac_model *m, int G) {
+    return (G >= 8 && m->h.naj > 0 && m->h_aj_type[0] == STAC_JNT_FREE && m->h_aj_qadr[0] == 0 && !m->dbg.nofree0) ? 1 : 0;
+}
+
 static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nchains, hipStream_t s) {
     stac_model *m = const_cast<stac_model *>(mc);
     if (p->maxiter < 1) return fail(STAC_ERR_INVALID, "maxiter must be >= 1");
@@ -814,6 +820,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 HIP_TRY(launch_ctl_init(m->d_ctl, 0, 0x7fffffff, 0, 0, (int)resident, s));
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
+            a.free0p = free0_ordinal_p1(m, sg);
             e = launch_q_phase(a, sg, sh.waves_per_block, 2, sr, lds, s, &cap);
             a.ctl = nullptr; a.queue_slots = 0;
         }
@@ -882,6 +889,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         if (hcap > 0) a.hand = m->d_hand;
         const int root_fast = a.root_fast;
         if ((a.flags & 2) || G < root_fast) a.root_fast = 0;  // root fast trips need the FK program and the root coordinates in register 0
+        a.free0p = free0_ordinal_p1(m, G);
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
         a.root_fast = root_fast;
         if (cap && e == hipSuccess && hcap > 0) {
@@ -894,6 +902,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             b.mb_words = q_mb_words(nkinds, kLatG);
             b.h.chain_stride = q_chain_stride(m->h, kLatG);
             int cap2 = 0;
+            b.free0p = free0_ordinal_p1(m, kLatG);
             e = launch_q_phase(b, kLatG, ss.waves_per_block, 2, kLatR, spec_lds_bytes(m->h, kLatG, nkinds, ss.chains_per_block, kLatR), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
             if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.waves_per_block);
@@ -1253,7 +1262,6 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
     a.n_run_root = do_root_opt ? m->n_run_root : 0;
     a.n_root_joints = n_root_joints;
-    a.root_free = -1;
     // Root fast trips (QArgs::root_fast): the root coordinates are the first root_dims (<= 8: register 0 of every lane
     // group of 8 or more lanes) and belong to leading joints that share ONE subtree range, whose weighted sites fit a 64-bit mask
     if (do_root_opt && m->n_mlev_root > 0 && n_root_joints >= 1 && n_root_joints < m->h.naj && root_dims <= 8 && K <= 64 && !m->dbg.nofast) {
@@ -1268,9 +1276,7 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
                 if (ts[i]) mask |= 1ull << i;
             a.root_fast = root_dims;
             a.root_trunk_lo = (uint32_t)mask; a.root_trunk_hi = (uint32_t)(mask >> 32);
-            if (n_root_joints == 1 && m->h_aj_type[0] == STAC_JNT_FREE && m->h_aj_qadr[0] == 0 && root_dims == 7) {
-                a.root_free = 0;  // active joint 0 is the first quaternion joint: ordinal 0 (JointRec::q0, build_plan)
-            }
+
         }
     }
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;

@@ -188,10 +188,10 @@ __device__ __forceinline__ void st_tvec2(float *p, V3 v) { st_tpos(p + kXq, v); 
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
 // naj_lim: the leading joints to do (all, or -- root fast trips -- only the joints of the root passes' coordinates).
 __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
-                                                    const int naj_lim) {
+                                                    const int naj_lim, const int j_first = 0) {
     const float *jrec = P + H.off_joint;
     float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *ja = CBc + H.c_ja, *qsv = CBc + H.c_qsv;
-    for (int j = lf; j < naj_lim; j += gf) {
+    for (int j = lf + j_first; j < naj_lim; j += gf) {
         const float *jr = jrec + 12 * j;
         const int4 ji = lds4i(jr);  // type, qadr, slo, shi
         const int ty = ji.x, ad = ji.y;

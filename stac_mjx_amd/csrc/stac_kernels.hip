@@ -354,34 +354,36 @@ void q_phase_kernel(const QArgs a) {
         // the world entry of the transform array (the gradient pass of the previous trip left its range sums there)
         if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
-        bool prepass_done = false;
-        if (lite && a.root_free >= 0) {
-            // The root passes' coordinates are ONE free joint at qpos 0 .. 6 (QArgs::root_free = its quaternion ordinal):
-            // staging and its pre-pass in one go, out of the registers of lanes 0 .. 6.  Every lane fetches the four raw
-            // quaternion components from lanes 3 .. 6 (one cross-lane round trip) and computes |q| itself -- the same fma
-            // chain as normalize4 -- so the four components are divided side by side and stored by their own lanes:
-            // {position, unit quaternion} into the joint's entry (the FK program's synthetic parent of the root body),
-            // the unit quaternion and |q| for the gradient pass, and the evaluation point as MJX writes it back.
-            const float pt = (st_in == ST_VG_Y) ? y[0] : ((st_in == ST_LS) ? CAND(0, lg) : x[0]);
-            const float mi = (mbits & 1u) ? 1.0f : 0.0f;
-            const float v = (1.0f - mi) * q0[0] + mi * pt;
-            const int gb = grp * G;
+        // A free joint at qpos 0 .. 6 (active joint 0: QArgs::free0p): its pre-pass out of the registers of lanes 0 .. 6, which
+        // hold the staged coordinates v.  Every lane fetches the four raw quaternion components from lanes 3 .. 6 (one
+        // cross-lane round trip) and computes |q| itself -- the same fma chain as normalize4 -- so the four components are
+        // divided side by side and stored by their own lanes: {position, unit quaternion} into the joint's entry (the FK
+        // program's synthetic parent of the root body), the unit quaternion and |q| for the gradient pass, and the
+        // evaluation point as MJX writes it back.  (One lane doing all of it, next to fifteen hinges, was the long pole
+        // of the pre-pass's first round.)
+        auto free0_prepass = [&](const float v, const int qord) {
+            const int gb = lane - lg;
             const float qw = __shfl(v, gb + 3, 64), qx = __shfl(v, gb + 4, 64), qy = __shfl(v, gb + 5, 64), qz = __shfl(v, gb + 6, 64);
             const float n = __builtin_sqrtf(FMA(qz, qz, FMA(qy, qy, FMA(qx, qx, qw * qw))));
             const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
-            float *ja0 = ja;  // active joint 0
             if (lg < 3) {
                 qe[lg] = v;
-                ja0[lg] = v;
+                ja[lg] = v;
             } else if (lg < 7) {
                 const float qn = v / dn;
                 const int c = lg - 3;  // 0 .. 3 = w, x, y, z
                 qe[lg] = qn;
-                ja0[kXq + (c == 0 ? 3 : c - 1)] = qn;  // entries hold (x, y, z, w)
-                qsv[4 * a.root_free + c] = qn;
-                if (c == 0) jn[a.root_free] = n;
+                ja[kXq + (c == 0 ? 3 : c - 1)] = qn;  // entries hold (x, y, z, w)
+                qsv[4 * qord + c] = qn;
+                if (c == 0) jn[qord] = n;
             }
-            prepass_done = true;
+        };
+        const int j0 = a.free0p ? 1 : 0;  // first joint of the per-joint loops
+        if (lite && a.free0p) {
+            // root fast trip on a free root: staging and the pre-pass in one go
+            const float pt = (st_in == ST_VG_Y) ? y[0] : ((st_in == ST_LS) ? CAND(0, lg) : x[0]);
+            const float mi = (mbits & 1u) ? 1.0f : 0.0f;
+            free0_prepass((1.0f - mi) * q0[0] + mi * pt, a.free0p - 1);
         } else if (lite) {
             if (lg < a.root_fast) {  // (the root coordinates are elements 0 .. root_fast - 1 <= G: register 0)
                 const float pt = (st_in == ST_VG_Y) ? y[0] : ((st_in == ST_LS) ? CAND(0, lg) : x[0]);
@@ -399,6 +401,7 @@ void q_phase_kernel(const QArgs a) {
             ubs[r] = UB(r, eb);
         }
         const float eta_s = (SPEC && st_in == ST_SPEC) ? eta * spec_pow : eta;  // eta / 2^c (exact)
+        float v0 = 0.0f;
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + lg;
@@ -408,14 +411,16 @@ void q_phase_kernel(const QArgs a) {
             else pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cr : x[r]);
             const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
             const float v = (1.0f - mi) * q0[r] + mi * pt;
-            if (e < nq) qe[e] = v;
+            if (r == 0) v0 = v;
+            if (e < nq && !(a.free0p && e < 7)) qe[e] = v;
         }
+        if (a.free0p) free0_prepass(v0, a.free0p - 1);
         }
         wave_sync();
         PROF_TICK(1);  // stage
 
-        if (!prepass_done) {
-            joint_local_prepass(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj);
+        if (!(lite && a.free0p)) {  // (a root fast trip on a free root has nothing else to prepare)
+            joint_local_prepass(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0);
             wave_sync();
         }
         PROF_TICK(10);  // joint-local pre-pass
@@ -649,8 +654,8 @@ void q_phase_kernel(const QArgs a) {
             }
             wave_sync();
             PROF_TICK(5);  // range sums
-            if (a.root_free >= 0) {
-                const float gv = free0_gradient(CB, cref, rid0, a.root_free);
+            if (a.free0p) {
+                const float gv = free0_gradient(CB, cref, rid0, a.free0p - 1);
                 if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
             } else {
                 for (int j = lg; j < a.n_root_joints; j += G) joint_gradient(j, CB, cref, gg);
@@ -669,12 +674,16 @@ void q_phase_kernel(const QArgs a) {
             wave_sync();
             PROF_TICK(5);  // range sums + zero gg
             const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
-            for (int j = lg; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
+            for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
             wave_sync();
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
                 if (e < nq && ((mbits >> r) & 1u)) gnew[r] = gg[e];
+            }
+            if (a.free0p) {  // the free root joint: one component per lane, its four divisions side by side
+                const float gv = free0_gradient(CB, cref, __builtin_bit_cast(int, jrec[11]), a.free0p - 1);
+                if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
             }
             wave_sync();
             PROF_TICK(6);  // joint gradients

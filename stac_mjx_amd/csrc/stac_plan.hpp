@@ -198,8 +198,9 @@ struct QArgs {
     // that finishes its root solves waits (ST_WAIT) until the other chains of its wavefront have, so that the root trips
     // of a wavefront are ALL fast ones and its chains start their pose solves in the same trip.
     int32_t root_fast;      // number of leading coordinates the root passes optimise (= root_dims), or 0
-    int32_t root_free;      // >= 0: those coordinates are ONE free joint (active joint 0, qpos 0 .. 6) and this is its ordinal
-                            // among the quaternion joints (staging and its pre-pass then run fused out of registers); else -1
+    int32_t free0p;         // > 0: active joint 0 is a free joint at qpos 0 .. 6 and free0p - 1 its ordinal among the quaternion
+                            // joints: lanes 0 .. 6 of a group (8 lanes or more) then run its pre-pass and its gradient out of
+                            // their registers, one component each, instead of one lane doing all of it (set per launch)
     uint32_t root_trunk_lo, root_trunk_hi;  // sorted-site positions inside the root joint's range that carry a weight
     // Straggler hand-off (null = off).  Chains take very different numbers of iterations; once most of a launch's
     // chains are done the rest would drag on at a few waves per CU.  ctl = {finished chains, threshold, handed-off
