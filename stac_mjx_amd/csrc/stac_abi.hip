@@ -28,6 +28,9 @@ hipError_t launch_m_partial(const FullModel &M, const float *kp, const float *xp
 hipError_t launch_m_finish(int K, const float *partial, const float *m0, const float *dreg, float lam, float *out,
                            float *err, hipStream_t s);
 hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4, hipStream_t s);
+hipError_t launch_chain_order(const float *kp, int C, int F, int K, const float *rest_sites, const uint8_t *kpw, int root_kp_idx,
+                              float rx, float ry, float rz, uint32_t *hist, uint32_t *keybits, int32_t *perm, int32_t *place,
+                              hipStream_t s);
 }  // namespace stac
 
 using namespace stac;
@@ -48,7 +51,7 @@ static int fail(int code, const std::string &msg) {
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
     int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
-    bool noprune = false, verbose = false, nofast = false, nofree0 = false;
+    bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
         return v ? atoi(v) : -1;
@@ -56,7 +59,7 @@ struct DebugSwitches {
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
         handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR");
-        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
+        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
 
@@ -75,6 +78,8 @@ struct stac_model {
     float *d_jnt_pos = nullptr, *d_jnt_axis = nullptr, *d_qpos0 = nullptr;
     int32_t *d_site_bodyid = nullptr;
     float *d_site_pos = nullptr;  // [K,3] offsets for the stand-alone FK / m-phase kernels (mirrors the plan's SiteRec.pos)
+    uint32_t *d_order = nullptr;  // chain order / placement work space: [3K floats rest sites][4096 buckets][kPlaceWords][C key bits][C perm]
+    size_t order_chains = 0;
     uint8_t *d_masks = nullptr;  // [kMaxKinds, nqpad] + [K] + [3K]
     std::vector<uint8_t> masks_cache;  // what d_masks currently holds (uploads + their sync happen only on change)
     // host copies of the plan's structure, used to build the LM solver's per-kind tables
@@ -552,6 +557,7 @@ constexpr long kSpec64MaxChains = 0, kSpec32MaxChains = 512;
 // iteration, but the four-lanes-per-position kinematics and fewer rounds in every per-item phase): measured 229 k against
 // 179 k frames/s on 1 000 x 250 clips for eight roles of 8 lanes (which stay behind STAC_HIP_SPECG=8)
 constexpr int kLatG = 16, kLatR = 4;
+constexpr int kOrderMinChains = 2048, kOrderMaxFrames = 8;  // stac_q_phase: chains ordered by expected length and placed by SIMD load
 // latency mode with 4 roles per chain from this many chains on (never auto-selected below: developer switch STAC_HIP_SPECR)
 constexpr long kSpec4MinChains = 1L << 40;
 
@@ -679,7 +685,7 @@ extern "C" void stac_model_destroy(stac_model *m) {
     DeviceGuard dg(m);
     void *ptrs[] = {m->d_bounds, m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
                     m->d_body_quat, m->d_jnt_type, m->d_jnt_qposadr, m->d_jnt_pos, m->d_jnt_axis,
-                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab, m->d_ctl, m->d_hand};
+                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab, m->d_ctl, m->d_hand, m->d_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -821,6 +827,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
             a.free0p = free0_ordinal_p1(m, sg);
+            a.perm = nullptr; a.place = nullptr;  // (latency mode: few chains, nothing to balance)
             e = launch_q_phase(a, sg, sh.waves_per_block, 2, sr, lds, s, &cap);
             a.ctl = nullptr; a.queue_slots = 0;
         }
@@ -890,8 +897,18 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         const int root_fast = a.root_fast;
         if ((a.flags & 2) || G < root_fast) a.root_fast = 0;  // root fast trips need the FK program and the root coordinates in register 0
         a.free0p = free0_ordinal_p1(m, G);
+        const int32_t *perm_in = a.perm;
+        int32_t *place_in = a.place;
+        {
+            const long waves = ((long)nchains * G + 63) / 64, simds = 4L * kCus;
+            const bool all_resident = qslots == 0 && waves <= (long)sh.waves_per_cu * kCus;
+            if (!(all_resident && waves > 2 * simds && waves % simds != 0)) { a.perm = nullptr; a.place = nullptr; }
+            else a.place_crowded = (int)(waves / simds) + 1;
+            if (dbg.verbose && a.place) fprintf(stderr, "[stac] q_phase: chains placed by SIMD load (crowded = %d wavefronts or more)\n", a.place_crowded);
+        }
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
         a.root_fast = root_fast;
+        a.perm = perm_in; a.place = place_in;
         if (cap && e == hipSuccess && hcap > 0) {
             // second launch: the latency kernel resumes whatever was handed off (waves without an entry exit at once)
             QArgs b = a;
@@ -1278,6 +1295,29 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
             a.root_trunk_lo = (uint32_t)mask; a.root_trunk_hi = (uint32_t)(mask >> 32);
 
         }
+    }
+    // Chain order + placement (QArgs::perm / place): large batches of short clips (the root solves are where chain lengths
+    // differ), rest pose as the start (no q_init), a free root at qpos 0 .. 6.  run_q keeps them only for a throughput launch
+    // whose wavefronts are all resident and unevenly spread over the SIMDs.
+    if (a.root_fast > 0 && m->h_aj_type[0] == STAC_JNT_FREE && m->h_aj_qadr[0] == 0 && !q_init && C >= kOrderMinChains &&
+        F <= kOrderMaxFrames && !m->dbg.noorder && p->solver == STAC_SOLVER_PG) {
+        const size_t words = (size_t)3 * K + 4096 + kPlaceWords + 2 * (size_t)C;
+        if ((size_t)C > m->order_chains) {
+            if (m->d_order) (void)hipFree(m->d_order);
+            m->d_order = nullptr; m->order_chains = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_order), words * sizeof(uint32_t)));
+            m->order_chains = (size_t)C;
+        }
+        float *rest = reinterpret_cast<float *>(m->d_order);
+        uint32_t *hist = m->d_order + 3 * K;
+        int32_t *place = reinterpret_cast<int32_t *>(hist + 4096);
+        uint32_t *keybits = reinterpret_cast<uint32_t *>(place + kPlaceWords);
+        int32_t *perm = reinterpret_cast<int32_t *>(keybits + m->order_chains);
+        const int rc2 = fk_impl(m, m->d_qpos0, 1, nullptr, nullptr, nullptr, rest, 1, stream);  // marker sites of the rest pose
+        if (rc2 != STAC_OK) return rc2;
+        const float *q0h = m->blob_host.data() + m->h.off_qpos0;  // rest position of the root body = its free joint's qpos0
+        HIP_TRY(launch_chain_order(kp, C, F, K, rest, d_kpw, root_kp_idx, q0h[0], q0h[1], q0h[2], hist, keybits, perm, place, s));
+        a.perm = perm; a.place = place;
     }
     a.qpos_out = qpos_out; a.err_out = err_out; a.counters_out = counters_out; a.q_carry_out = q_carry_out;
     a.kpw_sorted = d_kpw + K;

@@ -124,14 +124,46 @@ void q_phase_kernel(const QArgs a) {
     const int *quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
 
     // ---- per-chain solver state (uniform inside a group) ------------------------------------------
-    const int slot_id = SPEC ? (NW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * wpb + wave) * CW + cidx) : (int)(blockIdx.x * wpb + wave) * CPW + grp;
+    // Placement (QArgs::place; throughput launches whose wavefronts are all resident at once).  2 500 wavefronts on 1 024
+    // SIMDs: some SIMDs hold three, the others two, and a wavefront that shares its SIMD with two others runs its trips a
+    // quarter slower than one that shares it with one -- for the whole launch, the wavefronts never move.  With the chains
+    // in the order of their expected length (QArgs::perm) the wavefronts of the crowded SIMDs take the short chains and
+    // the others the long ones, so that both kinds finish together.  Every wavefront counts itself on its SIMD (HW_ID /
+    // XCC_ID), waits until all have (bounded: after the time-out it goes on with what it sees -- any outcome is a valid
+    // assignment), and draws its position from its kind's end of the order.
+    int wave_pos = (int)(blockIdx.x * wpb + wave);
+    if constexpr (!SPEC) {
+        if (a.place) {
+            int pos = 0;
+            if (lane == 0) {
+                const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;
+                const int key = (int)((xcc << 10) | (((hw >> 8) & 0xFFu) << 2) | ((hw >> 4) & 3u));  // XCC | SE, SH, CU | SIMD
+                int32_t *pl = a.place;
+                atomicAdd(pl + kPlaceHdr + key, 1);
+                __threadfence();
+                atomicAdd(pl, 1);
+                const int total = (int)(gridDim.x * wpb);
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                while (__hip_atomic_load(pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total &&
+                       __builtin_readcyclecounter() - t0 < 2000000ull)
+                    __builtin_amdgcn_s_sleep(32);
+                const int n = __hip_atomic_load(pl + kPlaceHdr + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool crowded = n >= a.place_crowded;
+                const int t = atomicAdd(pl + (crowded ? 1 : 2), 1);
+                pos = crowded ? t : total - 1 - t;
+            }
+            wave_pos = __builtin_amdgcn_readfirstlane(pos);
+        }
+    }
+    const int slot_id = SPEC ? (NW > 1 ? (int)blockIdx.x : (int)(blockIdx.x * wpb + wave) * CW + cidx) : wave_pos * CPW + grp;
     const int hstride = 3 * nqpad + 12;
     // resume = 1: this launch continues the chains that the throughput kernel handed off (QArgs::ctl / hand)
     const bool resuming = a.resume != 0 && slot_id < a.ctl[2] && slot_id < a.ctl[3];
     const float *hs = a.hand + (size_t)(resuming ? slot_id : 0) * hstride;
     const int *hi = reinterpret_cast<const int *>(hs + 3 * nqpad);
-    int chain = a.resume ? (resuming ? hi[0] : a.C) : slot_id;  // with a chain queue (QArgs::queue_slots) a group takes
-                                                                 // further chains when it has finished one
+    // (QArgs::perm: the launch's chains in the order the host wants them on the slots / in the queue)
+    int chain = a.resume ? (resuming ? hi[0] : a.C) : (slot_id < a.C && a.perm ? a.perm[slot_id] : slot_id);  // with a chain queue
+                                                                 // (QArgs::queue_slots) a group takes further chains when it has finished one
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
     int frame = 0, iter = 0, nls = 0;
@@ -1046,7 +1078,7 @@ void q_phase_kernel(const QArgs a) {
                                         if (SPEC ? (lane % LC) == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
                                         nxt = __shfl(nxt, SPEC ? (lane / LC) * LC : grp * G, 64);
                                     }
-                                    if (nxt < a.C) begin_chain(nxt);
+                                    if (nxt < a.C) begin_chain(a.perm ? a.perm[nxt] : nxt);
                                 }
                             }
                         } else {
@@ -1209,9 +1241,71 @@ __global__ void ctl_init_kernel(int32_t *ctl, int v0, int v1, int v2, int v3, in
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[0] = v0; ctl[1] = v1; ctl[2] = v2; ctl[3] = v3; ctl[4] = v4; ctl[5] = 0; ctl[6] = 0; ctl[7] = 0; }
 }
 
+// ---- chain order of a root-optimised launch (QArgs::perm) ----------------------------------------------------------------
+// How long a chain runs is mostly a matter of its root solves, and those of how far the clip's first frame is turned away
+// from the rest pose.  Its loss at the starting point -- rest pose moved to the root keypoint, trunk keypoints only; no
+// kinematics needed -- ranks the chains well enough (Spearman 0.88 with the number of evaluations on the bench batch): a
+// counting sort on the upper bits of that loss (4096 buckets; the order inside a bucket does not matter, and no result
+// depends on where a chain runs).  What the order is for: QArgs::place.
+constexpr int kKeyBuckets = 4096;
+__global__ void root_key_kernel(const float *kp, int C, int F, int K, const float *rest_sites, const uint8_t *kpw, int root_kp_idx,
+                                float rx, float ry, float rz, uint32_t *hist, uint32_t *keybits) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float *k0 = kp + (size_t)c * F * 3 * K;
+    const float sx = k0[3 * root_kp_idx] - rx, sy = k0[3 * root_kp_idx + 1] - ry, sz = k0[3 * root_kp_idx + 2] - rz;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        if (!kpw[k]) continue;
+        const float dx = k0[3 * k] - (rest_sites[3 * k] + sx), dy = k0[3 * k + 1] - (rest_sites[3 * k + 1] + sy),
+                    dz = k0[3 * k + 2] - (rest_sites[3 * k + 2] + sz);
+        acc += dx * dx + dy * dy + dz * dz;
+    }
+    uint32_t b = __builtin_bit_cast(uint32_t, acc) >> 19;  // sign 0: exponent + four mantissa bits, monotone in acc
+    if (!(acc == acc)) b = kKeyBuckets - 1;                 // NaN keypoints: last
+    b = b < (uint32_t)kKeyBuckets ? b : (uint32_t)kKeyBuckets - 1;
+    keybits[c] = b;
+    atomicAdd(hist + b, 1u);
+}
+__global__ __launch_bounds__(1024) void key_scan_kernel(uint32_t *hist) {  // exclusive prefix sum over the 4096 buckets, in place
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    uint32_t v[4], sum = 0;
+    for (int i = 0; i < 4; ++i) { v[i] = hist[4 * t + i]; sum += v[i]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int h = 1; h < 1024; h <<= 1) {
+        const uint32_t add = t >= h ? part[t - h] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int i = 0; i < 4; ++i) { hist[4 * t + i] = run; run += v[i]; }
+}
+__global__ void key_scatter_kernel(const uint32_t *keybits, uint32_t *offs, int C, int32_t *perm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    perm[atomicAdd(offs + keybits[c], 1u)] = c;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (called from stac_abi.hip)
 // ------------------------------------------------------------------------------------------------
+hipError_t launch_chain_order(const float *kp, int C, int F, int K, const float *rest_sites, const uint8_t *kpw, int root_kp_idx,
+                              float rx, float ry, float rz, uint32_t *hist, uint32_t *keybits, int32_t *perm, int32_t *place,
+                              hipStream_t s) {
+    hipError_t e = hipMemsetAsync(hist, 0, kKeyBuckets * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(place, 0, kPlaceWords * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    const int blocks = (C + 255) / 256;
+    hipLaunchKernelGGL(root_key_kernel, dim3(blocks), dim3(256), 0, s, kp, C, F, K, rest_sites, kpw, root_kp_idx, rx, ry, rz, hist, keybits);
+    hipLaunchKernelGGL(key_scan_kernel, dim3(1), dim3(1024), 0, s, hist);
+    hipLaunchKernelGGL(key_scatter_kernel, dim3(blocks), dim3(256), 0, s, keybits, hist, C, perm);
+    return hipGetLastError();
+}
+
 hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4, hipStream_t s) {
     hipLaunchKernelGGL(ctl_init_kernel, dim3(1), dim3(64), 0, s, ctl, v0, v1, v2, v3, v4);
     return hipGetLastError();

@@ -9,6 +9,7 @@
 
 namespace stac {
 
+constexpr int kPlaceHdr = 16, kPlaceWords = kPlaceHdr + 16 * 1024;  // QArgs::place: header, then one counter per (XCC, SE/SH/CU, SIMD)
 constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 // A lane of a G-lane group takes the sites k = r * G + lane, r < kSiteRounds: their keypoints and loss terms stay in
 // registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
@@ -183,6 +184,11 @@ struct QArgs {
     const uint8_t *kpw3;    // device [3K] per-coordinate mask for single-solve mode (or null)
     const uint8_t *kpw_sorted;  // device [K] trunk mask by sorted-site position (LM solver)
     const float *bounds;    // device [2 * nqpad] lb then ub overriding the plan's for this call (stac_q_solve), or null
+    const int32_t *perm;    // device [C] or null: slot / queue position -> chain, the chains in the order of their expected length
+                            // (stac_kernels.hip, root_key_kernel); results do not depend on it
+    int32_t *place;         // device [kPlaceWords] or null: placement work space {arrived, crowded tickets, other tickets, ...,
+                            // wavefronts per SIMD}: the wavefronts of crowded SIMDs take the short end of perm (q_phase_kernel)
+    int32_t place_crowded;  // a SIMD with this many wavefronts of the launch or more counts as crowded
     int32_t C, F, P;
     int32_t root_kp_idx, do_root_opt;
     int32_t single;         // 1 = stac_q_solve mode (one solve, outputs x unblended + state)
