@@ -1,0 +1,40 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash profiles/tools/collect_round.sh <round tag, e.g. r03>
+# Everything a round's numbers come from, in one go; results under gpurun_out/<tag>/ (copy what is to be judged into profiles/<tag>/):
+#   <tag>a_*      the default bench (BASELINE configs[1]): bench line, rocprofv3 kernel stats, five PMC passes
+#   <tag>clips_*  the same with the reference's default chaining (250 frames per clip)
+#   secondary.json   raw bench lines of the other configurations quoted in README / DESIGN
+#   lat_sweep.txt    latency-mode shapes against the automatic choice
+tag=$1
+R=$PWD
+OUT=$R/gpurun_out/$tag
+mkdir -p $OUT
+bash profiles/tools/collect_pmc.sh ${tag}a --steps 20 --warmup 5 > $OUT/collect_a.log 2>&1
+bash profiles/tools/collect_pmc.sh ${tag}clips --steps 2 --warmup 1 --frames-per-clip 250 --no-extras > $OUT/collect_clips.log 2>&1
+for t in a clips; do
+  mkdir -p $OUT/${tag}$t; cp gpurun_out/prof_${tag}$t/* $OUT/${tag}$t/ 2>/dev/null
+done
+{
+  echo "["
+  first=1
+  run() {  # label, args...
+    label=$1; shift
+    line=$(python3 bench.py --no-cpu-baseline --no-extras "$@" 2>/dev/null | tail -1)
+    [ -z "$line" ] && line='null'
+    [ $first = 1 ] || echo ","
+    first=0
+    echo "{\"label\": \"$label\", \"args\": \"$*\", \"line\": $line}"
+  }
+  run "100k frames, n_frames_per_clip=1" --frames 100000 --steps 3 --warmup 1
+  run "125k frames, n_frames_per_clip=250 (config 4 share)" --frames 125000 --frames-per-clip 250 --steps 1 --warmup 1
+  run "250k frames, n_frames_per_clip=250" --frames 250000 --frames-per-clip 250 --steps 1 --warmup 1
+  run "fly 10k frames" --model fly --steps 5 --warmup 2
+  run "mouse 10k frames" --model mouse --steps 2 --warmup 1
+  run "LM 10k frames" --solver lm --steps 10 --warmup 3
+  run "LM 100k frames" --solver lm --frames 100000 --steps 3 --warmup 1
+  run "LM 40 clips x 250" --solver lm --frames-per-clip 250 --steps 2 --warmup 1
+  run "fit mode, 1000 frames as 100 clips" --mode fit --frames 1000 --frames-per-clip 10 --steps 3 --warmup 1
+  echo "]"
+} > $OUT/secondary.json
+python3 profiles/tools/lat_sweep.py > $OUT/lat_sweep.txt 2>&1
+echo done

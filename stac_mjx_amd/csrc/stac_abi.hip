@@ -473,6 +473,14 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.off_qpos0 = put_fpad(t->qpos0, nq, h.nqpad);
     quat_adr.push_back(0);
     h.off_quat_adr = put_raw(quat_adr.data(), quat_adr.size());
+    {
+        std::vector<int32_t> act(h.nqpad, 0);
+        for (int j = 0; j < naj; ++j) {
+            const int dims = aj_type[j] == STAC_JNT_FREE ? 7 : (aj_type[j] == STAC_JNT_BALL ? 4 : 1);
+            for (int c = 0; c < dims; ++c) act[aj_qadr[j] + c] = 1;
+        }
+        h.off_active = put_raw(act.data(), act.size());
+    }
     h.core_words = (int)B.size();  // what a kernel that walks the levels itself stages in LDS
     // per-chain LDS layout
     int o = 0;
@@ -540,7 +548,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     return STAC_OK;
 }
 
-static int q_mb_words(int nkinds, int G) { return (nkinds * G + 3) & ~3; }
+static int q_mb_words(int nkinds, int G) { return ((nkinds + 1) * G + 3) & ~3; }  // per-kind mask bits + one row of active-coordinate bits
 static int q_chain_stride(const PlanHeader &h, int G) { return h.K <= kSiteRounds * G ? h.stride_regs : h.stride_lds; }
 static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
     const int plan_words = (h.total_words + 3) & ~3;  // h is the per-launch copy: total_words = what this launch stages
@@ -780,6 +788,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     const int nkinds = a.single ? 1 : a.P + 3;
     const DebugSwitches &dbg = m->dbg;
     if (dbg.flags >= 0) a.flags = dbg.flags;  // developer A/B switches (see stac_plan.hpp)
+    if (a.h.c_gg != a.h.c_sw || a.h.c_qe != a.h.c_sw) return fail(STAC_ERR_INVALID, "plan layout: the PG kernel expects c_qe == c_gg == c_sw");
 #ifdef STAC_PROFILE
     static unsigned long long *d_prof = nullptr;
     if (!d_prof) { (void)hipMalloc(reinterpret_cast<void **>(&d_prof), 16 * sizeof(unsigned long long)); }

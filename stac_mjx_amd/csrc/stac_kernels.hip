@@ -93,6 +93,16 @@ void q_phase_kernel(const QArgs a) {
         }
         MB[i] = bits;
     }
+    // one more row: the coordinates that belong to a joint of the active subtree (bit r <-> element r*G+lg): only those have
+    // a gradient entry, so the gradient vector needs no zeroing before the joint pass
+    for (int l = threadIdx.x; l < G; l += blockDim.x) {
+        uint32_t bits = 0;
+        for (int r = 0; r < NQR; ++r) {
+            const int e = r * G + l;
+            if (e < nq && __builtin_bit_cast(int, a.plan[H.off_active + e])) bits |= (1u << r);
+        }
+        MB[nkinds * G + l] = bits;
+    }
     // SPEC: a chain's block = 8 role regions + the exchange area; the block's waves share it (NW > 1) or own one each
     const int xch_words = 64 + 4 * nqpad + 4;
     const int cblock_words = NR * H.chain_stride + xch_words;
@@ -107,8 +117,9 @@ void q_phase_kernel(const QArgs a) {
         else wave_sync();
     };
     float *bx = CB + H.c_bx, *ja = CB + H.c_ja, *jn = CB + H.c_jn, *qsv = CB + H.c_qsv;
-    float *sw = CB + H.c_sw, *gg = CB + H.c_gg, *r2 = CB + H.c_r2;
-    float *qe = CB + H.c_qe, *kpl = CB + H.c_kp;
+    // (the evaluation point and the gradient vector live in the site-wrench region: c_qe == c_gg == c_sw in this kernel, run_q checks)
+    float *sw = CB + H.c_sw, *gg = sw, *r2 = CB + H.c_r2;
+    float *qe = sw, *kpl = CB + H.c_kp;
     // Sites k = r * G + lg, r < kSiteRounds, belong to this lane: their keypoints and loss terms stay in registers when
     // that covers all K sites (the host then lays the chain out without the c_kp / c_r2 regions); else through LDS.
     constexpr int NSR = kSiteRounds;
@@ -313,8 +324,8 @@ void q_phase_kernel(const QArgs a) {
         const int lg = lg_t;
         float *const CB = lds + cb_t;
         float *const bx = CB + H.c_bx, *const ja = CB + H.c_ja, *const jn = CB + H.c_jn, *const qsv = CB + H.c_qsv;
-        float *const sw = CB + H.c_sw, *const gg = CB + H.c_gg, *const r2 = CB + H.c_r2;
-        float *const qe = CB + H.c_qe, *const kpl = CB + H.c_kp;
+        float *const sw = CB + H.c_sw, *const gg = sw, *const r2 = CB + H.c_r2;
+        float *const qe = sw, *const kpl = CB + H.c_kp;
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
@@ -702,16 +713,15 @@ void q_phase_kernel(const QArgs a) {
             if constexpr (G >= 32) { for (int t = lg; t < 6 * H.nrange; t += G) range_task(t, CB); }
             else { for (int r = lg; r < H.nrange; r += G) range_sum(r, CB); }
             wave_sync();
-            for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
-            wave_sync();
-            PROF_TICK(5);  // range sums + zero gg
+            PROF_TICK(5);  // range sums
             const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
             for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
             wave_sync();
+            const uint32_t abits = MB[nkinds * G + lg] & mbits;  // optimised coordinates that HAVE a gradient entry
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
-                if (e < nq && ((mbits >> r) & 1u)) gnew[r] = gg[e];
+                if (e < nq && ((abits >> r) & 1u)) gnew[r] = gg[e];
             }
             if (a.free0p) {  // the free root joint: one component per lane, its four divisions side by side
                 const float gv = free0_gradient(CB, cref, __builtin_bit_cast(int, jrec[11]), a.free0p - 1);

@@ -126,6 +126,7 @@ struct PlanHeader {
     int32_t off_ub;        // [nqpad] float
     int32_t off_qpos0;     // [nqpad] float
     int32_t off_quat_adr;  // [nquat] qpos address of every quaternion (free: adr+3, ball: adr)
+    int32_t off_active;    // [nqpad] 1 where the coordinate belongs to a joint of the active subtree (only those get a gradient entry)
     int32_t total_words;   // words a launch stages in LDS (the per-launch copy may stop at core_words)
     int32_t core_words;    // blob without the FK program (the program is last)
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
