@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash profiles/tools/collect_pmc.sh <tag> [bench.py args...]
 # Writes gpurun_out/prof_<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py <args>`),
-# one JSON per PMC pass (counter passes are separate runs: the TCC counters do not fit one pass), bench.json.
+# one JSON per PMC pass (counter passes are separate runs of ONE step each: the TCC counters do not fit one pass), bench.json.
 tag=$1; shift
 R=$PWD
 OUT=$R/gpurun_out/prof_$tag
@@ -18,7 +18,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf /tmp/rp_${tag}_$i
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/rp_${tag}_$i --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /tmp/rp_${tag}_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/rp_${tag}_$i --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" --steps 1 --warmup 0 > /tmp/rp_${tag}_$i.log 2>&1
   python3 $R/profiles/tools/pmc_summary.py /tmp/rp_${tag}_$i q_phase > $OUT/pmc_pass$i.json
 done
 tail -1 $OUT/bench.json | cut -c1-200

@@ -9,6 +9,7 @@ tag=$1
 R=$PWD
 OUT=$R/gpurun_out/$tag
 mkdir -p $OUT
+cat stac_mjx_amd/csrc/libstac_hip.so.stamp > $OUT/lib_digest.txt
 bash profiles/tools/collect_pmc.sh ${tag}a --steps 20 --warmup 5 > $OUT/collect_a.log 2>&1
 bash profiles/tools/collect_pmc.sh ${tag}clips --steps 2 --warmup 1 --frames-per-clip 250 --no-extras > $OUT/collect_clips.log 2>&1
 for t in a clips; do
