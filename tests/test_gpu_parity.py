@@ -779,3 +779,57 @@ def test_latency_mode_four_roles_per_chain(rodent_setup, rodent_mocap, monkeypat
         res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
                           root_dims=fs.root_dims, do_root_opt=True)
         _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims))
+
+
+# ---- round 3: root fast trips, wave-synchronous root phase, chain order + placement by SIMD load ------------------------------
+@pytest.mark.parametrize("lanes", [8, 16, 32])
+@pytest.mark.parametrize("nofast", [None, "1"])
+def test_root_fast_trips_with_carried_poses_outside_the_box(rodent_setup, rodent_mocap, monkeypatch, lanes, nofast):
+    """Root optimisation from given start poses (q_init), some of whose NON-root coordinates lie outside their bounds: for
+    those chains the projected gradient moves unmasked coordinates in its first iteration (clip(y) != y), so their terms of
+    the solver's norms are not zero and the root fast trip must not be taken (tail_ok); the other chains of the same
+    wavefront take it.  Everything equals the oracle, with and without the fast path."""
+    if nofast:
+        monkeypatch.setenv("STAC_HIP_NOFAST", nofast)
+    fs = rodent_setup
+    eng, orc = _engine(fs, lanes_per_chain=lanes, maxiter=60), _oracle(fs, maxiter=60)
+    kp = rodent_mocap[300:322].reshape(22, 1, 69)
+    rng = np.random.default_rng(3)
+    q_init = np.tile(fs.tables.qpos0, (22, 1)).astype(np.float32)
+    q_init[:, 7:] += rng.normal(0, 0.05, (22, 67)).astype(np.float32)
+    q_init = np.clip(q_init, np.where(np.isfinite(fs.lb), fs.lb, -10), np.where(np.isfinite(fs.ub), fs.ub, 10)).astype(np.float32)
+    fin = np.flatnonzero(np.isfinite(fs.ub[7:])) + 7
+    for c in (1, 6, 7, 13, 21):  # chains with one or two coordinates beyond their upper / lower bound
+        q_init[c, fin[(3 * c) % len(fin)]] = fs.ub[fin[(3 * c) % len(fin)]] + 0.25
+        q_init[c, fin[(5 * c + 1) % len(fin)]] = fs.lb[fin[(5 * c + 1) % len(fin)]] - 0.1
+    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims,
+                      do_root_opt=True, q_init=q_init)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, q_init=q_init)
+    _compare_phase(res, ref)
+
+
+def test_chain_order_and_placement_by_simd_load(rodent_setup, rodent_mocap, monkeypatch):
+    """A batch large enough (2 100 wavefronts on 1 024 SIMDs) for the launch to order its chains by expected length and let
+    every wavefront pick its chains by the load of its SIMD (HW_ID count + bounded spin barrier): no result depends on
+    where a chain runs -- identical to the launch without the order, run to run, and equal to the oracle on sampled chains."""
+    fs = rodent_setup
+    C = 8400
+    rng = np.random.default_rng(17)
+    base = rodent_mocap[rng.integers(0, 1000, C)]
+    kp = (base + rng.normal(0, 2e-3, base.shape)).astype(np.float32).reshape(C, 1, 69)
+    args = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims,
+                do_root_opt=True, want_bodies=False)
+    eng = _engine(fs, maxiter=20)
+    a = eng.q_phase(kp, **args)
+    b = eng.q_phase(kp, **args)
+    for k in ("qpos", "frame_error", "counters", "marker_sites", "carry_qpos"):
+        assert (a[k] == b[k]).all(), k
+    monkeypatch.setenv("STAC_HIP_NOORDER", "1")
+    plain = _engine(fs, maxiter=20).q_phase(kp, **args)
+    for k in ("qpos", "frame_error", "counters", "marker_sites", "carry_qpos"):
+        assert (a[k] == plain[k]).all(), k
+    sel = [0, 1, 777, 4099, 4100, 8399]
+    ref = _oracle(fs, maxiter=20).ik_clips(kp[sel], fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, want_bodies=False)
+    for i, c in enumerate(sel):
+        np.testing.assert_array_equal(_np(a["qpos"][c]), ref["qpos"][i])
+        np.testing.assert_array_equal(_np(a["counters"][c]).astype(np.uint32), ref["counters"][i])
