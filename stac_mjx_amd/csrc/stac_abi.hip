@@ -618,6 +618,9 @@ static size_t spec_lds_bytes(const PlanHeader &h, int G, int nkinds, int chains,
     return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (nr * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float);
 }
 struct SpecShape { int G, chains_per_block, waves_per_block; long resident; };  // resident = chains the chip holds at once
+// The one-wavefront-per-chain latency kernel (kLatG lanes per role: straggler hand-off, large clip counts) exists up to 8
+// solver registers per lane (stac_kernels.hip, launch_q_phase); wider models run four wavefronts per chain and keep their stragglers
+static bool lat_one_wave_ok(const PlanHeader &h) { return h.nq <= 16 * 8; }
 static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nchains = -1, int nr = 8) {
     constexpr size_t kGranule = 1280;
     SpecShape best{G, 0, 0, 0};
@@ -675,7 +678,7 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_ctl), 8 * sizeof(int32_t)));
     {   // hand-off buffer of the straggler hand-off at its maximum size (one entry per wavefront the latency kernel
         // can hold resident), so that no launch ever reallocates (= waits for the device)
-        m->hand_cap = (int)pick_spec_shape(m->h, kLatG, 1, -1, kLatR).resident;
+        m->hand_cap = lat_one_wave_ok(m->h) ? (int)pick_spec_shape(m->h, kLatG, 1, -1, kLatR).resident : 0;
         if (m->hand_cap > 0)
             chk(hipMalloc(reinterpret_cast<void **>(&m->d_hand), (size_t)m->hand_cap * (3 * (size_t)m->h.nqpad + 12) * sizeof(float)));
     }
@@ -762,7 +765,8 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
-        const SpecShape ss = pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR);  // one chain per wave
+        const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR)  // one chain per wave
+                                                  : pick_spec_shape(m->h, 32, nkinds);
         if (ss.resident && (long)nchains * 10 <= ss.resident * 23) return 0;
     }
     const QShape s16 = pick_shape(m->h, 16, nkinds);
@@ -814,7 +818,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
         }
         if (dbg.specg == 8 || dbg.specg == 16 || dbg.specg == 32 || dbg.specg == 64) sg = dbg.specg;
-        if (m->h.nq > sg * (sg == 8 ? 32 : sg == 16 ? 16 : sg == 32 ? 8 : 4)) sg = 8;  // no instantiation that wide: back to one wave per chain
+        if (m->h.nq > sg * (sg == 8 ? 16 : 8) && sg < 32) sg = 32;  // no instantiation that wide at 8 / 16 lanes per role (stac_kernels.hip): four wavefronts per chain
         // roles per chain: four (two candidates + their momentum points, two chains per wavefront) once the batch is so
         // large that throughput counts, not the latency of one chain
         int sr = (sg == 8 && (long)nchains >= kSpec4MinChains) ? 4 : 8;
@@ -874,7 +878,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // mean), so the launch would end on a few waves per CU.  Once all but `hcap` chains are done, the rest move to
         // the latency kernel at their next iteration boundary (QArgs::ctl).
         int hcap = 0;
-        if (!a.single && !(a.flags & 3) && m->h.max_width <= kLatG) {
+        if (!a.single && !(a.flags & 3) && m->h.max_width <= kLatG && lat_one_wave_ok(m->h)) {
             const int spec_cap = (int)pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR).resident;
             // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
             if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
@@ -889,7 +893,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             const int per_block = sh.wpb * (64 / G), want = dbg.queue;
             if (!a.single && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
         }
-        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= kLatG && dbg.handoff < 0) {
+        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= kLatG && dbg.handoff < 0 && lat_one_wave_ok(m->h)) {
             hcap = std::min((int)pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR).resident, nchains / 5);  // with a queue the tail is one round: hand off
         }
         hcap = std::min(hcap, m->hand_cap);
@@ -911,8 +915,13 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         {
             const long waves = ((long)nchains * G + 63) / 64, simds = 4L * kCus;
             const bool all_resident = qslots == 0 && waves <= (long)sh.waves_per_cu * kCus;
-            if (!(all_resident && waves > 2 * simds && waves % simds != 0)) { a.perm = nullptr; a.place = nullptr; }
-            else a.place_crowded = (int)(waves / simds) + 1;
+            if (all_resident && waves > 2 * simds && waves % simds != 0) a.place_crowded = (int)(waves / simds) + 1;
+            else {
+                a.place = nullptr;
+                // with a chain queue the order still serves: the queue hands the chains out longest first, four of similar
+                // length per wavefront (which takes its next four together: q_phase_kernel, ST_NEXT)
+                if (!(qslots > 0 && a.root_fast > 0)) a.perm = nullptr;
+            }
             if (dbg.verbose && a.place) fprintf(stderr, "[stac] q_phase: chains placed by SIMD load (crowded = %d wavefronts or more)\n", a.place_crowded);
         }
         e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);

@@ -109,7 +109,7 @@ __device__ __forceinline__ float group_tree_sum(const float (&v)[NQR]) {
     return t[0];
 }
 
-enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4, ST_WAIT = 5 };
+enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4, ST_WAIT = 5, ST_NEXT = 6 };
 
 // In-kernel phase stamps: diagnostic build only (-DSTAC_PROFILE -> libstac_hip_prof.so); the stamps
 // go to a buffer of their own and feed no output.  Read the SHARES, not the run time.

@@ -173,7 +173,9 @@ void q_phase_kernel(const QArgs a) {
     const float *hs = a.hand + (size_t)(resuming ? slot_id : 0) * hstride;
     const int *hi = reinterpret_cast<const int *>(hs + 3 * nqpad);
     // (QArgs::perm: the launch's chains in the order the host wants them on the slots / in the queue)
-    int chain = a.resume ? (resuming ? hi[0] : a.C) : (slot_id < a.C && a.perm ? a.perm[slot_id] : slot_id);  // with a chain queue
+    // queue position -> chain: with a queue the chains go out longest first (perm is ascending), the short ones fill the end
+    auto queue_chain = [&](const int pos) { return a.perm ? a.perm[(!SPEC && a.queue_slots > 0) ? a.C - 1 - pos : pos] : pos; };
+    int chain = a.resume ? (resuming ? hi[0] : a.C) : (slot_id < a.C && a.perm ? queue_chain(slot_id) : slot_id);  // with a chain queue
                                                                  // (QArgs::queue_slots) a group takes further chains when it has finished one
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
@@ -361,12 +363,28 @@ void q_phase_kernel(const QArgs a) {
         if constexpr (!SPEC) {
             // wave-synchronous root phase: chains that have finished their root solves go on when no chain of the
             // wavefront is in one any more
-            const bool root_live = st != ST_DONE && st != ST_WAIT && !a.single && kind < 2;
+            const bool root_live = st != ST_DONE && st != ST_WAIT && st != ST_NEXT && !a.single && kind < 2;
             const bool any_root_live = __any(root_live);  // (all lanes vote: not inside the condition below)
             if (st == ST_WAIT && !any_root_live) st = ST_VG_Y;
+            // chain queue with root fast trips: the groups of a wavefront take their next chains TOGETHER, when all of them
+            // have finished (ST_NEXT), so that the root solves of the new chains run as fast trips too (the queue hands the
+            // chains out in the order of their expected length: the four of a wavefront finish close to each other)
+            if (a.queue_slots > 0 && a.root_fast > 0) {
+                const bool busy = st != ST_DONE && st != ST_NEXT;
+                if (!__any(busy) && __any(st == ST_NEXT)) {
+                    if (st == ST_NEXT) {
+                        int nxt = 0;
+                        if (lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
+                        nxt = __shfl(nxt, grp * G, 64);
+                        if (nxt < a.C) begin_chain(queue_chain(nxt));
+                        else st = ST_DONE;
+                    }
+                    if (!__any(st != ST_DONE)) break;
+                }
+            }
         }
         const int st_in = st;
-        const bool live_in = st_in != ST_DONE && st_in != ST_WAIT;
+        const bool live_in = st_in != ST_DONE && st_in != ST_WAIT && (SPEC || st_in != ST_NEXT);
         const uint32_t mbits = MB[kind * G + lg];
         // A line-search candidate that is accepted becomes x_next, whose gradient the stopping test
         // needs (the oracle's separate VG_X evaluation runs the very same FK).  The step size doubles
@@ -713,11 +731,15 @@ void q_phase_kernel(const QArgs a) {
             if constexpr (G >= 32) { for (int t = lg; t < 6 * H.nrange; t += G) range_task(t, CB); }
             else { for (int r = lg; r < H.nrange; r += G) range_sum(r, CB); }
             wave_sync();
+            if constexpr (SPEC != 0) {  // (latency kernels: the bootstrap evaluation of a solve is rare; they keep the zeroed vector)
+                for (int e = lg; e < nqpad; e += G) gg[e] = 0.0f;
+                wave_sync();
+            }
             PROF_TICK(5);  // range sums
             const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
             for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
             wave_sync();
-            const uint32_t abits = MB[nkinds * G + lg] & mbits;  // optimised coordinates that HAVE a gradient entry
+            const uint32_t abits = SPEC ? mbits : (MB[nkinds * G + lg] & mbits);  // optimised coordinates that HAVE a gradient entry
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
@@ -1084,11 +1106,14 @@ void q_phase_kernel(const QArgs a) {
                                         __syncthreads();
                                         nxt = xq[0];
                                         __syncthreads();
+                                    } else if (!SPEC && a.root_fast > 0) {
+                                        st = ST_NEXT;  // with its wavefront's other groups, at the top of the loop
+                                        nxt = a.C;
                                     } else {
                                         if (SPEC ? (lane % LC) == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
                                         nxt = __shfl(nxt, SPEC ? (lane / LC) * LC : grp * G, 64);
                                     }
-                                    if (nxt < a.C) begin_chain(a.perm ? a.perm[nxt] : nxt);
+                                    if (nxt < a.C) begin_chain(queue_chain(nxt));
                                 }
                             }
                         } else {
@@ -1101,7 +1126,7 @@ void q_phase_kernel(const QArgs a) {
                             if (e < 3) q0[r] = a.kp[kp_chain + 3 * a.root_kp_idx + e];  // root passes run on frame 0
                         }
                     }
-                    if (st != ST_DONE) {
+                    if (st != ST_DONE && (SPEC || st != ST_NEXT)) {
 #pragma unroll
                         for (int r = 0; r < NQR; ++r) { x[r] = q0[r]; y[r] = q0[r]; }
                         stepsize = 1.0f; t = 1.0f; iter = 0;
@@ -1350,9 +1375,14 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
         *capacity_out = GG * RR;                                     \
         return launch_q<GG, RR, WW, NRR>(a, wpb, lds_bytes, s);      \
     }
-        STAC_TRY_SPEC(8, 10, 2, 4) STAC_TRY_SPEC(8, 16, 2, 4) STAC_TRY_SPEC(8, 32, 2, 4)
-        STAC_TRY_SPEC(8, 10, 2, 8) STAC_TRY_SPEC(8, 16, 2, 8) STAC_TRY_SPEC(8, 32, 2, 8)
-        STAC_TRY_SPEC(16, 5, 2, 4) STAC_TRY_SPEC(16, 8, 2, 4) STAC_TRY_SPEC(16, 16, 2, 4)
+        // Latency-kernel instantiations stop at 16 solver registers per lane at 8 lanes and 8 at 16: the wider ones (32 / 16
+        // registers per vector, six vectors: hundreds of bytes of scratch per lane) turned out to depend on what the
+        // previous launch left behind -- a value reloaded from a spill slot before it is stored, moving from one shape to
+        // the other with unrelated source changes (round 3; tests/test_gpu_parity.py::_q_phase_twice).  Wide models
+        // (mouse: nq = 230) take 32 or 64 lanes per role instead.
+        STAC_TRY_SPEC(8, 10, 2, 4) STAC_TRY_SPEC(8, 16, 2, 4)
+        STAC_TRY_SPEC(8, 10, 2, 8) STAC_TRY_SPEC(8, 16, 2, 8)
+        STAC_TRY_SPEC(16, 5, 2, 4) STAC_TRY_SPEC(16, 8, 2, 4)
         STAC_TRY_SPEC(32, 3, 2, 8) STAC_TRY_SPEC(32, 8, 2, 8)
         STAC_TRY_SPEC(64, 2, 2, 8) STAC_TRY_SPEC(64, 4, 2, 8)
 #undef STAC_TRY_SPEC

@@ -112,6 +112,17 @@ def test_q_solve_random_masks_bit_exact(rodent_setup, rodent_mocap, seed):
 
 
 # ---- the q_phase drivers ---------------------------------------------------------------------------------
+def _q_phase_twice(eng, kp, **kw):
+    """Run the launch twice on the same engine and require identical outputs: the second launch finds the scratch memory
+    (register spills) as the first one left it, so a value read before it is written shows up here (it did: round 3)."""
+    a = eng.q_phase(kp, **kw)
+    b = eng.q_phase(kp, **kw)
+    for k in ("qpos", "frame_error", "counters", "carry_qpos", "marker_sites", "xpos"):
+        if a.get(k) is not None:
+            assert (a[k] == b[k]).all(), f"second launch differs in {k}"
+    return b
+
+
 def _compare_phase(res, ref, bodies=True):
     np.testing.assert_array_equal(_np(res["counters"]).astype(np.uint32), ref["counters"])
     np.testing.assert_array_equal(_np(res["qpos"]), ref["qpos"])
@@ -129,8 +140,8 @@ def test_q_phase_ik_clips_bit_exact(rodent_setup, rodent_mocap, lanes):
     fs = rodent_setup
     eng, orc = _engine(fs, lanes_per_chain=lanes), _oracle(fs)
     kp = rodent_mocap[:9 * 3].reshape(9, 3, 69)  # 9 clips (ragged vs lanes), 3 frames
-    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                      root_dims=fs.root_dims, do_root_opt=True)
+    res = _q_phase_twice(eng, kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                         root_dims=fs.root_dims, do_root_opt=True)
     ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
     _compare_phase(res, ref)
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
@@ -170,8 +181,8 @@ def test_q_phase_register_cap_variants(rodent_setup, rodent_mocap, monkeypatch, 
     fs = rodent_setup
     eng, orc = _engine(fs, lanes_per_chain=16, maxiter=40), _oracle(fs, maxiter=40)
     kp = rodent_mocap[700:745].reshape(45, 1, 69)  # 45 chains: 12 waves, a partly filled last wave
-    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                      root_dims=fs.root_dims, do_root_opt=True)
+    res = _q_phase_twice(eng, kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                         root_dims=fs.root_dims, do_root_opt=True)
     _compare_phase(res, orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims))
 
 
@@ -185,8 +196,8 @@ def test_q_phase_straggler_handoff(rodent_setup, rodent_mocap, monkeypatch, fram
     fs = rodent_setup
     eng, orc = _engine(fs, lanes_per_chain=16, maxiter=60), _oracle(fs, maxiter=60)
     kp = rodent_mocap[500:500 + 44 * frames].reshape(44, frames, 69)
-    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                      root_dims=fs.root_dims, do_root_opt=True)
+    res = _q_phase_twice(eng, kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                         root_dims=fs.root_dims, do_root_opt=True)
     ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
     _compare_phase(res, ref)
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
@@ -297,8 +308,8 @@ def test_q_phase_mouse_model(mouse_setup, lanes):
     qt[:, 3:7] = fs.tables.qpos0[3:7]
     kp = np.stack([orc.fk(q)["site_xpos"].reshape(-1) for q in qt]).reshape(3, 1, 102)
     kp = kp + rng.normal(0, 5e-4, kp.shape).astype(np.float32)
-    res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                      root_dims=fs.root_dims, do_root_opt=fs.do_root_opt)
+    res = _q_phase_twice(eng, kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                         root_dims=fs.root_dims, do_root_opt=fs.do_root_opt)
     ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims,
                        do_root_opt=fs.do_root_opt)
     _compare_phase(res, ref)
@@ -720,8 +731,8 @@ def test_latency_mode_wavefronts_per_chain(rodent_setup, fly_setup, mouse_setup,
     for maxls in (15, 2):
         eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=60, maxls=maxls)
         orc = Oracle(fs.tables, tol=1e-4, maxiter=60, maxls=maxls)
-        res = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                          root_dims=fs.root_dims, do_root_opt=True)
+        res = _q_phase_twice(eng, kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
+                             root_dims=fs.root_dims, do_root_opt=True)
         ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
         _compare_phase(res, ref)
         np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
@@ -733,7 +744,7 @@ def test_latency_mode_wavefronts_per_chain(rodent_setup, fly_setup, mouse_setup,
     qt[:, 3:7] = fly.tables.qpos0[3:7]
     kpf = np.stack([orcf.fk(q)["site_xpos"].reshape(-1) for q in qt]).reshape(2, 3, 90)
     kpf = kpf + rng.normal(0, 1e-3, kpf.shape).astype(np.float32)
-    _compare_phase(engf.q_phase(kpf, part_masks=fly.part_masks),
+    _compare_phase(_q_phase_twice(engf, kpf, part_masks=fly.part_masks),
                    orcf.ik_clips(kpf, fly.lb, fly.ub, fly.part_masks, fly.trunk_kps, 0, 7, do_root_opt=False))
     # mouse: nq = 230 (four solver registers per lane at 64 lanes), 85 tree levels
     ms = mouse_setup
@@ -741,8 +752,8 @@ def test_latency_mode_wavefronts_per_chain(rodent_setup, fly_setup, mouse_setup,
     qm = ms.tables.qpos0[None] + np.clip(rng.normal(0, 0.05, (2, 230)), -0.1, 0.1).astype(np.float32)
     qm[:, 3:7] = ms.tables.qpos0[3:7]
     kpm = np.stack([orcm.fk(q)["site_xpos"].reshape(-1) for q in qm]).reshape(2, 1, 102)
-    _compare_phase(engm.q_phase(kpm, part_masks=ms.part_masks, trunk_kps=ms.trunk_kps, root_kp_idx=ms.root_kp_idx,
-                                root_dims=ms.root_dims, do_root_opt=ms.do_root_opt),
+    _compare_phase(_q_phase_twice(engm, kpm, part_masks=ms.part_masks, trunk_kps=ms.trunk_kps, root_kp_idx=ms.root_kp_idx,
+                                  root_dims=ms.root_dims, do_root_opt=ms.do_root_opt),
                    orcm.ik_clips(kpm, ms.lb, ms.ub, ms.part_masks, ms.trunk_kps, ms.root_kp_idx, ms.root_dims,
                                  do_root_opt=ms.do_root_opt))
 
