@@ -410,6 +410,18 @@ void q_phase_kernel(const QArgs a) {
         // root fast trip: only the root coordinates are staged and only the root joint's local transform is refreshed
         // (lite) once the other joints' local quaternions sit untouched in their ja entries
         const bool fast_trip = !SPEC && a.root_fast > 0 && n_ml_root > 0;
+        if (fast_trip && !tail_ok) {
+            // A chain whose start pose has coordinates outside the box (mouse: ranges that do not contain the rest angle)
+            // moves them onto the box in the first iteration of the solve; from then on x = y sits inside and the lite
+            // transition is exact for it as well (the kinematics never see x or y of a coordinate that is not optimised)
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < NQR; ++r) {
+                const int e = r * G + lg;
+                if (e < nq && e >= a.root_fast && !(x[r] == y[r] && x[r] >= lbv[e] && x[r] <= ubv[e])) ok = false;
+            }
+            tail_ok = ok;
+        }
         const bool lite = fast_trip && !__any(live_in && !ql_fresh);
 
         // the world entry of the transform array (the gradient pass of the previous trip left its range sums there)
@@ -1132,6 +1144,7 @@ void q_phase_kernel(const QArgs a) {
                         stepsize = 1.0f; t = 1.0f; iter = 0;
                         error = __builtin_inff();
                         st = ST_VG_Y;
+                        if (!SPEC && a.root_fast > 0 && kind < 2) check_tail();  // the next root solve starts from q0 again
                         // root solves over: the pose solves begin when the wavefront's other chains are there too (top of the loop)
                         if (!SPEC && a.root_fast > 0 && was_root && kind == 2) st = ST_WAIT;
                     }
