@@ -51,7 +51,7 @@ static int fail(int code, const std::string &msg) {
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
     int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
-    bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false;
+    bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false, nodiet = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
         return v ? atoi(v) : -1;
@@ -59,7 +59,7 @@ struct DebugSwitches {
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
         handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR");
-        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
+        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; nodiet = getenv("STAC_HIP_NODIET") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
 
@@ -551,7 +551,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
 static int q_mb_words(int nkinds, int G) { return ((nkinds + 1) * G + 3) & ~3; }  // per-kind mask bits + one row of active-coordinate bits
 static int q_chain_stride(const PlanHeader &h, int G) { return h.K <= kSiteRounds * G ? h.stride_regs : h.stride_lds; }
 static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
-    const int plan_words = (h.total_words + 3) & ~3;  // h is the per-launch copy: total_words = what this launch stages
+    const int plan_words = (h.total_words - h.plan_skip + 3) & ~3;  // h is the per-launch copy: [plan_skip, total_words) = what this launch stages
     return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * q_chain_stride(h, G)) * sizeof(float);
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -614,7 +614,7 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_need
 static int spec_xch_words(const PlanHeader &h) { return 64 + 4 * h.nqpad + 4; }
 // nr = evaluation roles per chain: 8, or 4 (two chains per wavefront at 8 lanes per role: large batches)
 static size_t spec_lds_bytes(const PlanHeader &h, int G, int nkinds, int chains, int nr = 8) {
-    const int plan_words = (h.total_words + 3) & ~3;
+    const int plan_words = (h.total_words - h.plan_skip + 3) & ~3;
     return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (nr * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float);
 }
 struct SpecShape { int G, chains_per_block, waves_per_block; long resident; };  // resident = chains the chip holds at once
@@ -858,18 +858,26 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // lane group and the workgroups that fit a CU stay the same; else the kernel walks the levels itself.
         const long waves_needed = ((long)nchains * G + 63) / 64;
         a.h.total_words = m->h.core_words;
+        a.h.plan_skip = 0;
         QShape sh = pick_shape(a.h, G, nkinds, waves_needed);
         if (!sh.wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
         a.flags |= 2;
         if (m->h.max_width <= G && !(dbg.flags >= 0 && (dbg.flags & 2))) {
             PlanHeader hp = m->h;
+            // LDS diet of a program launch: no level tables / body records (they come first in the blob), and of the root
+            // program (last) only the steps this call's trunk keypoints need -- or nothing without root optimisation
+            if (m->h.off_lev_adr == 0 && m->h.off_body < m->h.off_joint && !dbg.nodiet) {
+                hp.plan_skip = m->h.off_joint;
+                const int root_words = (a.do_root_opt && a.n_mlev_root > 0) ? m->h.fk_hdr_words + a.n_mlev_root * m->h.max_width * m->h.fk_rec_words : 0;
+                hp.total_words = m->h.off_fkroot + root_words;
+            }
             const QShape shp = pick_shape(hp, G, nkinds, waves_needed);
             // same residency, or every wave resident anyway -- or at least 60 % of the waves: a wave on the program runs
             // its kinematics about twice as fast as one that walks the level tables (mouse, 85 levels: 3 waves per CU on
             // the program 24.0 k frames/s, 5 on the level loop 22.0 k)
             if (shp.wpb && (shp.waves_per_cu >= sh.waves_per_cu || (long)shp.waves_per_cu * kCus >= waves_needed ||
                             shp.waves_per_cu * 10 >= sh.waves_per_cu * 6)) {
-                sh = shp; a.h.total_words = m->h.total_words; a.flags &= ~2;
+                sh = shp; a.h.total_words = hp.total_words; a.h.plan_skip = hp.plan_skip; a.flags &= ~2;
             }
         }
         if (dbg.wpe >= 0) sh.wpe = dbg.wpe >= 4 ? 4 : (dbg.wpe == 3 && G == 16) ? 3 : 2;

@@ -71,8 +71,8 @@ void q_phase_kernel(const QArgs a) {
     const int nq = H.nq, K = H.K, nqpad = H.nqpad;
 
     // ---- stage the plan into LDS (shared by the block's wavefronts) ------------------------------------
-    float *P = lds;
-    for (int i = threadIdx.x; i < H.total_words; i += blockDim.x) {
+    float *P = lds - H.plan_skip;  // (the words in front of plan_skip are not staged: nothing of this launch reads them)
+    for (int i = H.plan_skip + threadIdx.x; i < H.total_words; i += blockDim.x) {
         float v = a.plan[i];
         if (a.bounds) {  // per-call lb / ub of stac_q_solve (StacCore.q_opt takes them per call, stac_core.py:193-235)
             if (i >= H.off_lb && i < H.off_lb + nqpad) v = a.bounds[i - H.off_lb];
@@ -80,7 +80,7 @@ void q_phase_kernel(const QArgs a) {
         }
         P[i] = v;
     }
-    const int plan_words = (H.total_words + 3) & ~3;
+    const int plan_words = (H.total_words - H.plan_skip + 3) & ~3;
     // per-kind qs_to_opt bit masks, one 32-bit word per (kind, lane-in-group): bit r <-> element r*G+lg
     uint32_t *MB = reinterpret_cast<uint32_t *>(lds + plan_words);
     const int nkinds = a.single ? 1 : a.P + 3;
