@@ -10,6 +10,8 @@ built to reproduce the float32 oracle operation for operation, so these tests as
 import numpy as np
 import pytest
 
+from conftest import GOLDEN
+
 pytestmark = pytest.mark.gpu
 
 TOL_NORTH_STAR = 1e-4  # BASELINE.json north_star: "within 1e-4"
@@ -170,6 +172,26 @@ def test_q_phase_fk_program_and_level_loop_agree(rodent_setup, fly_setup, rodent
     kpf = kpf + rng.normal(0, 1e-3, kpf.shape).astype(np.float32)
     resf = engf.q_phase(kpf, part_masks=fly.part_masks)
     _compare_phase(resf, orcf.ik_clips(kpf, fly.lb, fly.ub, fly.part_masks, fly.trunk_kps, 0, 7, do_root_opt=False))
+
+
+@pytest.mark.parametrize("flags", ["0", "2", "4"])
+@pytest.mark.parametrize("lanes", [16, 32])
+@pytest.mark.parametrize("nodiet", [None, "1"])
+def test_q_phase_fk_implementations_agree_on_the_mouse(mouse_setup, monkeypatch, flags, lanes, nodiet):
+    """The same for the mouse (86-step program, 181 active joints, start pose outside the box for some ranges, root
+    optimisation with root fast trips): program, program through the dispatch, level loop; with and without the LDS diet of
+    a program launch (no level tables / body records staged, root program only as far as used).  Launched twice."""
+    monkeypatch.setenv("STAC_HIP_FLAGS", flags)
+    if nodiet:
+        monkeypatch.setenv("STAC_HIP_NODIET", nodiet)
+    ms = mouse_setup
+    real = np.load(GOLDEN / "mouse_mocap_200.npy")
+    kp = real[[3, 40, 77, 120, 160, 199]].reshape(3, 2, 102)
+    eng, orc = _engine(ms, lanes_per_chain=lanes, maxiter=30), _oracle(ms, maxiter=30)
+    res = _q_phase_twice(eng, kp, part_masks=ms.part_masks, trunk_kps=ms.trunk_kps, root_kp_idx=ms.root_kp_idx,
+                         root_dims=ms.root_dims, do_root_opt=ms.do_root_opt)
+    _compare_phase(res, orc.ik_clips(kp, ms.lb, ms.ub, ms.part_masks, ms.trunk_kps, ms.root_kp_idx, ms.root_dims,
+                                     do_root_opt=ms.do_root_opt))
 
 
 @pytest.mark.parametrize("wpe,wpb", [("2", "3"), ("3", "10"), ("4", "5"), ("4", "8")])
