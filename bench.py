@@ -313,7 +313,12 @@ def main():
                     "algorithmic_flops_per_step": flops, "algorithmic_flop_per_lane_slot": flops / lane_slots,
                     "useful_lane_fraction": (flops / 2.0) / lane_slots,  # one FMA = 2 flop per lane-slot at best
                     "valu_issue_busy_frac": ent["sq_insts_valu"] * 2.0 / (1024 * 2.4e9 * kern_ms * 1e-3),
-                    "note": "wave64 VALU instruction = 2 issue cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz; busy = issued / available"}
+                    # what the hardware counts: SQ_ACTIVE_INST_VALU is in quad-cycles (MI355X_MICROARCH.md, s_memtime row) and comes out
+                    # at one per VALU instruction here, i.e. 4 cycles of a SIMD's vector pipe each -- the figure that explains why a
+                    # SIMD with three wavefronts of this kernel runs them a quarter slower than one with two (placement)
+                    "valu_active_frac": (ent["sq_active_inst_valu"] * 4.0 / (1024 * 2.4e9 * kern_ms * 1e-3)) if ent.get("sq_active_inst_valu") else None,
+                    "note": "valu_issue_busy_frac: wave64 VALU instruction = 2 issue cycles on a SIMD-32 (the guide's throughput figure); "
+                            "valu_active_frac: SQ_ACTIVE_INST_VALU quad-cycles x 4; 1024 SIMDs at 2.4 GHz"}
     except (FileNotFoundError, KeyError):
         pass
     if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and F == 1 and not args.no_extras:

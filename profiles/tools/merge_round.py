@@ -60,7 +60,8 @@ def main():
     for leg, fpc in (("a", 1), ("clips", 250)):
         valu["entries"].append({"frames": 10000, "frames_per_clip": fpc, "model": "rodent", "sq_insts_valu": tot(per[leg], "SQ_INSTS_VALU"),
                                 "sq_insts_salu": tot(per[leg], "SQ_INSTS_SALU"), "sq_insts_lds": tot(per[leg], "SQ_INSTS_LDS"),
-                                "sq_insts_branch": tot(per[leg], "SQ_INSTS_BRANCH"), "lib_digest": digest,
+                                "sq_insts_branch": tot(per[leg], "SQ_INSTS_BRANCH"),
+                                "sq_active_inst_valu": tot(per[leg], "SQ_ACTIVE_INST_VALU"), "lib_digest": digest,
                                 "source": f"profiles/{tag}/{tag}{leg}_pmc.json"})
     (ROOT / "profiles" / "valu.json").write_text(json.dumps(valu, indent=1) + "\n")
     fk, wk = tot(per["a"], "FETCH_SIZE"), tot(per["a"], "WRITE_SIZE")
