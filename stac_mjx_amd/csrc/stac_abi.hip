@@ -50,7 +50,7 @@ static int fail(int code, const std::string &msg) {
 // Developer switches: read from the environment ONCE, at stac_model_create, so that a variable
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
-    int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1;
+    int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1, stride_add = -1;
     bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false, nodiet = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
@@ -58,7 +58,7 @@ struct DebugSwitches {
     }
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
-        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR");
+        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR"); stride_add = geti("STAC_HIP_STRIDE_ADD");
         noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; nodiet = getenv("STAC_HIP_NODIET") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
@@ -511,10 +511,11 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     // wavefront start in different banks
     auto stride_of = [](int words) { const int q = (words + 3) / 4; return kXf == 8 ? 4 * (q | 1) : (words | 1); };
     o = (o + 3) & ~3;
-    h.stride_regs = stride_of(o);
+    h.stride_regs = stride_of(o) + std::max(m->dbg.stride_add, 0);
+    h.stride_forced = m->dbg.stride_add >= 0;
     h.c_r2 = o; o += K > 64 ? h.kpow2 : ((K + 3) & ~3);
     h.c_kp = o; o += 3 * K;
-    h.stride_lds = stride_of(o);
+    h.stride_lds = stride_of(o) + std::max(m->dbg.stride_add, 0);
 
     {   // FK program (FkStep records, see stac_plan.hpp); a second area of the same size takes the pruned program of
         // the root passes, which depends on the call's trunk keypoints (fill_root_program)
@@ -549,7 +550,15 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
 }
 
 static int q_mb_words(int nkinds, int G) { return ((nkinds + 1) * G + 3) & ~3; }  // per-kind mask bits + one row of active-coordinate bits
-static int q_chain_stride(const PlanHeader &h, int G) { return h.K <= kSiteRounds * G ? h.stride_regs : h.stride_lds; }
+// (G = 16: two chains share a 32-lane half of the wavefront, and the 32-bit LDS accesses bank by word address mod 32 per
+// half: a stride of 16 mod 32 puts the second chain's run of 16 consecutive words on the other 16 banks.  Measured on the
+// bench, profiles/r03/stride_sweep.txt: conflict cycles 25 % -> 16 % of the LDS-active ones; time within the noise,
+// as it is for a stride of 0 mod 32 with 46 % -- the conflicts are not what the kernel waits for.)
+static int q_chain_stride(const PlanHeader &h, int G) {
+    int s = h.K <= kSiteRounds * G ? h.stride_regs : h.stride_lds;
+    if (G == 16 && kXf == 7 && !h.stride_forced) s += (16 - s % 32 + 32) % 32;
+    return s;
+}
 static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
     const int plan_words = (h.total_words - h.plan_skip + 3) & ~3;  // h is the per-launch copy: [plan_skip, total_words) = what this launch stages
     return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * q_chain_stride(h, G)) * sizeof(float);

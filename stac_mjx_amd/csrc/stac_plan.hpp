@@ -148,6 +148,7 @@ struct PlanHeader {
     int32_t c_r2;      // [K padded] per-site loss terms           } sites per lane: else both stay in registers
     int32_t stride_regs, stride_lds;  // chain stride without / with those two regions (odd)
     int32_t chain_stride;  // the one of this launch (set per launch by the host)
+    int32_t stride_forced; // STAC_HIP_STRIDE_ADD given: the strides are taken as they are (profiling)
     int32_t max_width; // bodies in the widest level
     int32_t nst;       // bodies whose transform is stored in LDS (a site or a child on another lane reads it)
     int32_t nqj;       // active quaternion joints (free / ball)
