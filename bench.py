@@ -180,6 +180,7 @@ def main():
                          "ranks with the offset-phase all-reduce over RCCL (stac.fit_frames_per_clip), reported as frame-solves/s")
     ap.add_argument("--solver", default="pg", choices=["pg", "lm"],
                     help="pg = the reference's projected gradient (parity mode, the BASELINE metric); lm = optional fast solver")
+    ap.add_argument("--lm-maxiter", type=int, default=20, help="--solver lm: accepted LM steps per solve (engine default 20)")
     ap.add_argument("--model", default="rodent", choices=["rodent", "fly", "mouse"],
                     help="rodent = the BASELINE metric; fly / mouse = other fixtures (reported under config, not the headline)")
     args = ap.parse_args()
@@ -213,7 +214,7 @@ def main():
     F = args.frames_per_clip
     C = args.frames // F
     eng = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), lanes_per_chain=args.lanes,
-                 device=f"cuda:{local_rank}", solver=args.solver)
+                 device=f"cuda:{local_rank}", solver=args.solver, lm_maxiter=args.lm_maxiter)
     # synthetic batch (seeded per rank), generated with the engine's own FK, then offsets fixed
     eng.set_site_pos(synth_offsets(fs))
     fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
@@ -279,7 +280,7 @@ def main():
                         f"{fs.tables.nsite} keypoints, {frames_step} synthetic frames per GPU, "
                         f"q_phase only ({'root opt + ' if fs.do_root_opt else ''}full + {len(fs.part_masks)} part PG solves per frame), n_frames_per_clip={F} "
                         f"({C} independent chains), FTOL={cfg['FTOL']}, N_ITER_Q={cfg['N_ITER_Q']}, "
-                        + ("solver=pg (parity mode)" if args.solver == "pg" else "solver=lm (NOT the reference's algorithm; marker-space quality only)"),
+                        + ("solver=pg (parity mode)" if args.solver == "pg" else f"solver=lm, at most {args.lm_maxiter} steps per solve (NOT the reference's algorithm; marker-space quality only)"),
             "frames_per_gpu": frames_step, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
             "parallelism": f"clips sharded over {world} GPU(s), no data-path collective",
             "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
@@ -352,7 +353,7 @@ def main():
         # the north star words the q_phase as a Levenberg-Marquardt update; the reference runs projected gradient (the
         # `value` above, parity mode).  The optional LM solver on the same resident batch, for the record -- never `value`.
         lm = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), device=f"cuda:{local_rank}",
-                    solver="lm")
+                    solver="lm", lm_maxiter=args.lm_maxiter)
         lm.set_site_pos(synth_offsets(fs))
         lo = None
         lev = []
@@ -370,6 +371,7 @@ def main():
         line["config"]["lm_solver_same_batch"] = {
             "frames_per_s": frames_step / (lm_ms * 1e-3), "kernel_ms": lm_ms,
             "marker_rmse_mm": float(torch.sqrt((lerr ** 2).mean()).item() * 1e3),
+            "lm_maxiter": args.lm_maxiter,
             "note": "stac_q_params.solver = STAC_SOLVER_LM; not the reference's algorithm, judged in marker space only"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.solver == "pg":
         line["cpu_baseline"] = cpu_baseline(fs, cfg, kp_host)

@@ -30,7 +30,7 @@ _STAC_REQUIRED = (
 _STAC_OPTIONAL = ("num_clips",)
 _MUJOCO_REQUIRED = ("solver", "iterations", "ls_iterations")
 # Engine extensions (not in the reference schema); all optional.
-_STAC_EXTENSIONS = ("solver", "lanes_per_chain", "device", "time_indices", "fit_frames_per_clip", "reference_marker_order", "gather", "gather_max_bytes")
+_STAC_EXTENSIONS = ("solver", "lanes_per_chain", "device", "time_indices", "fit_frames_per_clip", "reference_marker_order", "gather", "gather_max_bytes", "lm_maxiter")
 _MODEL_EXTENSIONS = ("KP_NAMES_LABEL3D_PATH",)
 
 

@@ -111,7 +111,7 @@ class Engine:
     """One compiled model resident on one GPU."""
 
     def __init__(self, tables, lb, ub, *, tol=1e-4, maxiter=400, maxls=15, lanes_per_chain=0, device=None,
-                 solver="pg", lm_maxiter=40, lm_lambda0=1e-2):
+                 solver="pg", lm_maxiter=20, lm_lambda0=1e-2):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise StacHipError("no GPU visible: the STAC engine has no CPU fallback")

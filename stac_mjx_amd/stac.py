@@ -43,7 +43,8 @@ class Stac:
         # least as well, but does not reproduce the reference's truncated iterates).
         self.engine = Engine(s.tables, s.lb, s.ub, tol=float(cfg.model.FTOL), maxiter=int(cfg.model.N_ITER_Q),
                              lanes_per_chain=int(stac_cfg.get("lanes_per_chain", 0) or 0), device=device,
-                             solver=str(stac_cfg.get("solver", "pg") or "pg"))
+                             solver=str(stac_cfg.get("solver", "pg") or "pg"),
+                             lm_maxiter=int(stac_cfg.get("lm_maxiter", 20) or 20))
         self.stac_core_obj = StacCore(self.engine, float(cfg.model.FTOL), int(cfg.model.N_ITER_Q))
         self._offsets = torch.as_tensor(s.tables.site_pos.copy())
         self._timestep = s.tables.timestep
