@@ -38,4 +38,6 @@ done
   echo "]"
 } > $OUT/secondary.json
 python3 profiles/tools/lat_sweep.py > $OUT/lat_sweep.txt 2>&1
+python3 profiles/tools/lat_sweep.py fly 100 40 256 500 1000 2000 > $OUT/lat_sweep_fly.txt 2>&1
+python3 profiles/tools/lat_sweep.py mouse 20 40 256 500 1000 > $OUT/lat_sweep_mouse.txt 2>&1
 echo done

@@ -47,8 +47,9 @@ def main():
                        f"library build {digest[:16]}")
         (dst / f"{tag}{leg}_pmc.json").write_text(json.dumps(pm, indent=1) + "\n")
         per[leg] = pm
-    for f in ("secondary.json", "lat_sweep.txt"):
-        shutil.copy(src / f, dst / f)
+    for f in ("secondary.json", "lat_sweep.txt", "lat_sweep_fly.txt", "lat_sweep_mouse.txt"):
+        if (src / f).exists():
+            shutil.copy(src / f, dst / f)
 
     def tot(pm, c):
         return sum(v.get(c, 0.0) for k, v in pm.items() if isinstance(v, dict) and "q_phase_kernel" in k)
