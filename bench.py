@@ -117,13 +117,15 @@ def run_fit_mode(args, rank, local_rank, world, dist):
     solves = world * C * F * n_pass * args.steps
     d_off = float(np.linalg.norm(data.offsets - synth_offsets(fs), axis=-1).mean() * 1e3)
     line = {
-        "metric": "frame-solves/sec STAC fit_offsets (rodent, 23 kp), clip-parallel calibration",
+        "metric": "frame-solves/sec STAC fit_offsets (rodent, 23 kp), " + ("one chain" if C == 1 else "clip-parallel calibration"),
         "value": solves / elapsed, "unit": "frame-solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"Stac.fit_offsets, stac.fit_frames_per_clip={F}: {C * F} frames per GPU as {C} clips, N_ITERS={n_pass - 1} "
-                        f"(+ final pass), PG parity mode; NOT the reference's single-chain sequencing (engine extension)",
+                        f"(+ final pass), PG parity mode; "
+                        + ("one warm-started chain per GPU = the reference's own sequencing (stac.py:298-311)" if C == 1
+                           else "NOT the reference's single-chain sequencing (engine extension)"),
             "frames_per_gpu": C * F, "fit_frames_per_clip": F,
             "parallelism": f"clips sharded over {world} GPU(s); offset phase: one all-reduce of {3 * fs.tables.nsite + 2} floats per "
                            f"calibration iteration ({n_pass - 1} per fit)",

@@ -35,6 +35,7 @@ done
   run "LM 100k frames" --solver lm --frames 100000 --steps 3 --warmup 1
   run "LM 40 clips x 250" --solver lm --frames-per-clip 250 --steps 2 --warmup 1
   run "fit mode, 1000 frames as 100 clips" --mode fit --frames 1000 --frames-per-clip 10 --steps 3 --warmup 1
+  run "fit mode, one chain of 1000 frames (reference sequencing, config 3)" --mode fit --frames 1000 --frames-per-clip 1000 --steps 1 --warmup 0
   echo "]"
 } > $OUT/secondary.json
 python3 profiles/tools/lat_sweep.py > $OUT/lat_sweep.txt 2>&1
