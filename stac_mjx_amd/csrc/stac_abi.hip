@@ -549,6 +549,16 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     return STAC_OK;
 }
 
+// LDS diet (PlanHeader::plan_skip): the offsets of the staged areas as the kernel sees them, from the first staged word
+static void rebase_plan_offsets(PlanHeader &h) {
+    const int sk = h.plan_skip;
+    if (sk <= 0) return;
+    int32_t *offs[] = {&h.off_joint, &h.off_site, &h.off_range, &h.off_lb, &h.off_ub, &h.off_qpos0, &h.off_quat_adr,
+                       &h.off_active, &h.off_fkstep, &h.off_fkroot};
+    for (int32_t *o : offs) *o -= sk;
+    h.off_lev_adr = h.off_body = 0;  // not staged (nothing of a program launch reads them)
+}
+
 static int q_mb_words(int nkinds, int G) { return ((nkinds + 1) * G + 3) & ~3; }  // per-kind mask bits + one row of active-coordinate bits
 // (G = 16: two chains share a 32-lane half of the wavefront, and the 32-bit LDS accesses bank by word address mod 32 per
 // half: a stride of 16 mod 32 puts the second chain's run of 16 consecutive words on the other 16 banks.  Measured on the
@@ -949,7 +959,13 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             }
             if (dbg.verbose && a.place) fprintf(stderr, "[stac] q_phase: chains placed by SIMD load (crowded = %d wavefronts or more)\n", a.place_crowded);
         }
-        e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, q_lds_bytes(a.h, G, nkinds, sh.wpb), s, &cap);
+        {
+            const size_t lds_bytes = q_lds_bytes(a.h, G, nkinds, sh.wpb);
+            const PlanHeader h_keep = a.h;
+            rebase_plan_offsets(a.h);
+            e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, lds_bytes, s, &cap);
+            a.h = h_keep;
+        }
         a.root_fast = root_fast;
         a.perm = perm_in; a.place = place_in;
         if (cap && e == hipSuccess && hcap > 0) {

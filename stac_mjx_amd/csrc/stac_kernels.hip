@@ -71,9 +71,12 @@ void q_phase_kernel(const QArgs a) {
     const int nq = H.nq, K = H.K, nqpad = H.nqpad;
 
     // ---- stage the plan into LDS (shared by the block's wavefronts) ------------------------------------
-    float *P = lds - H.plan_skip;  // (the words in front of plan_skip are not staged: nothing of this launch reads them)
-    for (int i = H.plan_skip + threadIdx.x; i < H.total_words; i += blockDim.x) {
-        float v = a.plan[i];
+    // The launch stages the words [plan_skip, total_words) of the blob; the host has rebased every off_* of this launch's
+    // header to the first staged word (run_q), so P is the LDS base itself -- never a pointer in front of it: a lambda
+    // that the compiler does not inline reads through a flat pointer, and below the LDS aperture that is a fault.
+    float *P = lds;
+    for (int i = threadIdx.x; i < H.total_words - H.plan_skip; i += blockDim.x) {
+        float v = a.plan[H.plan_skip + i];
         if (a.bounds) {  // per-call lb / ub of stac_q_solve (StacCore.q_opt takes them per call, stac_core.py:193-235)
             if (i >= H.off_lb && i < H.off_lb + nqpad) v = a.bounds[i - H.off_lb];
             else if (i >= H.off_ub && i < H.off_ub + nqpad) v = a.bounds[nqpad + i - H.off_ub];
@@ -99,7 +102,7 @@ void q_phase_kernel(const QArgs a) {
         uint32_t bits = 0;
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + l;
-            if (e < nq && __builtin_bit_cast(int, a.plan[H.off_active + e])) bits |= (1u << r);
+            if (e < nq && __builtin_bit_cast(int, a.plan[H.plan_skip + H.off_active + e])) bits |= (1u << r);
         }
         MB[nkinds * G + l] = bits;
     }

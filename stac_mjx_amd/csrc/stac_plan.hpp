@@ -129,8 +129,8 @@ struct PlanHeader {
     int32_t off_active;    // [nqpad] 1 where the coordinate belongs to a joint of the active subtree (only those get a gradient entry)
     int32_t total_words;   // end of what a launch stages in LDS (the per-launch copy may stop at core_words, or inside the root program)
     int32_t plan_skip;     // ... and its beginning (per launch): a kernel that runs the FK program does not need the level tables and
-                           // body records in front of the joint records, so the LDS copy starts at off_joint (P = lds - plan_skip keeps
-                           // every offset valid)
+                           // body records in front of the joint records, so the LDS copy starts at off_joint; the launch's header copy then carries
+                           // every off_* of a staged area minus plan_skip (rebase_plan_offsets, stac_abi.hip)
     int32_t core_words;    // blob without the FK program (the program is last)
     // per-chain LDS layout (float offsets inside one chain's region) ------------------------------
     int32_t c_bx;      // [(nst+1)*kXf] transform entries of the stored bodies; entry 0 = world

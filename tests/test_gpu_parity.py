@@ -639,10 +639,13 @@ def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_
         site_names=[f"s{i}" for i in range(K)])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", list(range(12)) + [129])
 def test_random_models_bit_exact(seed):
     """Random trees (3-40 bodies, chains and bushes, free or fixed root, slides, every third one with ball joints)
-    through FK and the q_phase at several lane-group sizes: HIP == oracle bit for bit."""
+    through FK and the q_phase at several lane-group sizes: HIP == oracle bit for bit.  (Seed 129, found by
+    tests/fuzz_random_models.py in round 3: nq = 81 at 4 lanes per chain, an instantiation in which the compiler keeps a
+    lambda out of line -- its reads of the plan go through flat pointers, which faulted while the plan pointer of a
+    program launch pointed in front of the LDS base.)"""
     from oracle import Oracle
     from stac_mjx_amd.engine import Engine
     from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE, JNT_QPOS_DIMS
