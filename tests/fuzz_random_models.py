@@ -7,9 +7,14 @@ sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import pytest
 import test_gpu_parity as T
 bad = 0; ran = 0
+big = len(sys.argv) > 2 and sys.argv[2] == "big"  # `N big`: the large-tree / many-chain flavour (test_random_models_large_trees_many_chains)
 for seed in range(12, 12 + int(sys.argv[1])):
     try:
-        T.test_random_models_bit_exact(seed); ran += 1
+        if big:
+            T._random_model_case(seed, 40, 110, int((7, 70, 300)[seed % 3]), 1 + seed % 3, (8, 16, 32, 64, 0), q_init=bool(seed % 2))
+        else:
+            T.test_random_models_bit_exact(seed)
+        ran += 1
     except pytest.skip.Exception:
         pass
     except Exception as e:

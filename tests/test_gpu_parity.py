@@ -692,6 +692,79 @@ def test_random_models_bit_exact(seed):
         _compare_phase(res, ref)
 
 
+def _random_model_case(seed, nbody_lo, nbody_hi, chains, frames, lanes_list, maxiter=10, q_init=False):
+    """One random model through the q_phase at the given lane widths, each launched twice, against the oracle."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine, StacHipError
+    from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE, JNT_QPOS_DIMS
+
+    rng = np.random.default_rng(50000 + seed)
+    free_root = bool(rng.integers(2))
+    t = _random_tables(rng, int(rng.integers(nbody_lo, nbody_hi + 1)), free_root, p_ball=float(rng.choice([0.0, 0.1])),
+                       max_children_bias=float(rng.choice([0.05, 0.3, 0.6, 0.9, 0.97])))
+    nq, K = t.nq, t.nsite
+    if nq == 0:
+        pytest.skip("no joints drawn")
+    lb, ub = np.full(nq, -np.inf, np.float32), np.full(nq, np.inf, np.float32)
+    for j in range(t.njnt):
+        a, ty = int(t.jnt_qposadr[j]), int(t.jnt_type[j])
+        if ty == JNT_FREE:
+            lb[a + 3:a + 7], ub[a + 3:a + 7] = -1, 1
+        elif ty == JNT_BALL:
+            lb[a:a + 4], ub[a:a + 4] = -1, 1
+        else:
+            lb[a], ub[a] = min(t.jnt_range[j, 0], 0.0), t.jnt_range[j, 1]
+    tol = float(rng.choice([1e-5, 1e-3]))
+    orc = Oracle(t, tol=tol, maxiter=maxiter)
+    n = chains * frames
+    q = np.tile(t.qpos0, (n, 1)) + rng.normal(0, 0.15, (n, nq)).astype(np.float32)
+    q = np.clip(q, np.where(np.isfinite(lb), lb, -3), np.where(np.isfinite(ub), ub, 3)).astype(np.float32)
+    kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32)
+    kp = (kp + rng.normal(0, 2e-3, kp.shape)).astype(np.float32).reshape(chains, frames, 3 * K)
+    P = int(rng.integers(0, 4))
+    part = np.zeros((P, nq), np.uint8)
+    for i in range(P):
+        part[i] = rng.random(nq) < rng.choice([0.15, 0.5])
+    trunk = (rng.random(K) < 0.6).astype(np.uint8)
+    trunk[0] = 1
+    qi = q.reshape(chains, frames, nq)[:, 0].copy() if q_init else None
+    kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=free_root and not q_init)
+    ref = orc.ik_clips(kp, lb, ub, part, trunk, 0, 7, do_root_opt=kw["do_root_opt"], q_init=qi)
+    ran = 0
+    for lanes in lanes_list:
+        try:
+            eng = Engine(t, lb, ub, tol=tol, maxiter=maxiter, lanes_per_chain=lanes)
+            res = _q_phase_twice(eng, kp, q_init=qi, **kw)
+        except StacHipError as e:  # a lane width that cannot hold this model (capacity) is refused, not mis-run
+            assert "limits" in str(e) or "lanes" in str(e) or "capacity" in str(e).lower(), e
+            continue
+        _compare_phase(res, ref)
+        if lanes == lanes_list[-1]:  # the solver seam (stac_q_solve = StacCore.q_opt) on the same model: random masks, a per-call box
+            ns = min(n, 6)
+            qs = (rng.random(nq) < 0.6).astype(np.uint8)
+            ks = (rng.random(3 * K) < 0.8).astype(np.uint8)
+            fin = np.isfinite(lb) & np.isfinite(ub)
+            lb2, ub2 = lb.copy(), ub.copy()
+            lb2[fin], ub2[fin] = lb[fin] * 0.5, ub[fin] * 0.5
+            kpf = kp.reshape(n, 3 * K)[:ns]
+            q0s = np.clip(q[:ns], np.where(np.isfinite(lb2), lb2, -3), np.where(np.isfinite(ub2), ub2, 3)).astype(np.float32)
+            par, st, cn = eng.q_solve(kpf, q0s, qs, ks, lb=lb2, ub=ub2)
+            for i in range(ns):
+                xr, sr = orc.q_opt(kpf[i], qs, ks, q0s[i], lb2, ub2)
+                np.testing.assert_array_equal(_np(par)[i], xr)
+                assert int(_np(cn)[i, 0]) == sr["iter_num"] and float(_np(st)[i, 0]) == np.float32(sr["error"])
+        eng.close()
+        ran += 1
+    assert ran > 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_models_large_trees_many_chains(seed):
+    """Larger random trees (40-110 bodies: nq up to ~200, the wide instantiations), 70 chains x 2 frames (more chains than a
+    workgroup holds; with a carried start pose on odd seeds), every lane width, each launch repeated: HIP == oracle bit for bit."""
+    _random_model_case(seed, 40, 110, 70, 2, (8, 16, 32, 64, 0), q_init=bool(seed % 2))
+
+
 # ---- boundary details ---------------------------------------------------------------------------------------------------
 def test_q_solve_per_call_bounds(rodent_setup, rodent_mocap):
     """StacCore.q_opt takes lb / ub per call (stac_core.py:193-235, hyperparams_proj): a box passed to stac_q_solve
