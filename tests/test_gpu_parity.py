@@ -149,6 +149,37 @@ def test_q_phase_ik_clips_bit_exact(rodent_setup, rodent_mocap, lanes):
     np.testing.assert_array_equal(_np(res["carry_qpos"]), ref["qpos"][:, -1])
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("lanes,solver", [(16, "pg"), (0, "pg"), (0, "lm")])
+def test_q_phase_missing_keypoints_terminate_and_stay_in_their_chain(rodent_setup, rodent_mocap, lanes, solver):
+    """Mocap files carry NaN for markers the cameras lost.  The reference has no guard (jaxopt then iterates on NaN); what the
+    engine owes is (a) every launch ends -- NaN compares false everywhere, so the stopping test, the line search and the LM
+    accept rule all fall through -- and (b) the damage stays in the chain that has the NaN: the other chains of the same
+    wavefront are bit-identical to a launch without it, and to the oracle."""
+    from stac_mjx_amd.engine import Engine
+
+    fs = rodent_setup
+    kp = rodent_mocap[100:100 + 8 * 3].reshape(8, 3, 69).copy()
+    args = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=True)
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=40, lanes_per_chain=lanes, solver=solver, lm_maxiter=10)
+    keys = ("qpos", "frame_error", "counters", "marker_sites")
+    clean = {k: _np(v) for k, v in eng.q_phase(kp, **args).items() if k in keys}
+    dirty_kp = kp.copy()
+    dirty_kp[2, 1, 3 * 5:3 * 5 + 3] = np.nan   # a limb marker, second frame of chain 2
+    dirty_kp[5, 0, 3 * fs.root_kp_idx] = np.nan  # the root marker's x, first frame of chain 5 (the root solves start from it)
+    dirty = {k: _np(v) for k, v in eng.q_phase(dirty_kp, **args).items() if k in keys}
+    keep = [c for c in range(8) if c not in (2, 5)]
+    for k in keys:
+        np.testing.assert_array_equal(dirty[k][keep], clean[k][keep], err_msg=k)
+    np.testing.assert_array_equal(dirty["qpos"][2, 0], clean["qpos"][2, 0])  # the frame before the NaN is untouched too
+    if solver == "pg":
+        ref = _oracle(fs, maxiter=40).ik_clips(dirty_kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+        np.testing.assert_array_equal(dirty["qpos"][keep], ref["qpos"][keep])
+        np.testing.assert_array_equal(dirty["counters"][keep].astype(np.uint32), ref["counters"][keep])
+        # (what a chain does AFTER its NaN is not compared: where a NaN survives a clip or a select is not part of the contract)
+    eng.close()
+
+
 @pytest.mark.parametrize("flags", ["0", "2", "4"])
 @pytest.mark.parametrize("lanes", [4, 16, 32])
 def test_q_phase_fk_program_and_level_loop_agree(rodent_setup, fly_setup, rodent_mocap, monkeypatch, flags, lanes):
