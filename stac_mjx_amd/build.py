@@ -15,7 +15,8 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libstac_hip.so"
 SOURCES = [CSRC / "stac_kernels.hip", CSRC / "stac_lm.hip", CSRC / "stac_abi.hip"]
 HEADERS = [CSRC / "stac_plan.hpp", CSRC / "stac_device.hpp", CSRC.parents[1] / "include" / "stac_hip.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-fno-slp-vectorize"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-fno-slp-vectorize",
+         "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
 FLAGS += os.environ.get("STAC_HIP_EXTRA_FLAGS", "").split()
 
 
