@@ -781,12 +781,16 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 // i.e. the latency mode up to about 2.3 x its resident capacity, then 32 lanes until the 16-lane kernel has
 // about 45 % of its slots filled (8 and 4 lanes only on request: with the LDS footprint of a chain they cannot
 // keep two waves per SIMD resident).  Returns 0 for the latency mode.
-static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed) {
+static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed, int frames) {
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
         const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR)  // one chain per wave
                                                   : pick_spec_shape(m->h, 32, nkinds);
-        if (ss.resident && (long)nchains * 10 <= ss.resident * 23) return 0;
+        // Measured crossover against the throughput kernel (rodent, profiles/r03/shape_sweep.txt): 1.8 x the resident chains
+        // for single-frame clips, 2.3 x for two or three frames, 2.6 x from four frames on (the longer a clip, the less
+        // of it are the root solves that the throughput kernel runs as fast trips)
+        const long x10 = frames <= 1 ? 18 : (frames < 4 ? 23 : 26);
+        if (ss.resident && (long)nchains * 10 <= ss.resident * x10) return 0;
     }
     const QShape s16 = pick_shape(m->h, 16, nkinds);
     {   // Models whose chains are so large that 16-lane groups leave a wavefront or less per SIMD (mouse: 6.9 KB of LDS per chain,
@@ -797,7 +801,7 @@ static int pick_lanes(const stac_model *m, int requested, int nchains, int nkind
             (long)nchains * 100 > (long)s32.waves_per_cu * kCus * 2 * 45)
             return 32;
     }
-    if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 45) return 16;
+    if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 25) return 16;  // (from a quarter of the resident slots on: 16 lanes beat 32 at every measured size above the latency kernel's range)
     if (nchains > 2500 && pick_shape(m->h, 32, nkinds).wpb) return 32;
     return 64;
 }
@@ -826,7 +830,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), s);
     a.prof = d_prof;
 #endif
-    int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds, !a.single);
+    // (clip length for the latency / throughput crossover; without root optimisation -- the tethered fly -- a single-frame clip
+    //  has no root solves for the throughput kernel to run as fast trips: counted like a two-frame clip, measured)
+    int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds, !a.single, a.single ? 1 : (a.do_root_opt ? a.F : std::max(a.F, 2)));
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
     // Latency mode: when there are so few chains that each would get a whole wavefront anyway (G = 64), let
@@ -950,7 +956,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         {
             const long waves = ((long)nchains * G + 63) / 64, simds = 4L * kCus;
             const bool all_resident = qslots == 0 && waves <= (long)sh.waves_per_cu * kCus;
-            if (all_resident && waves > 2 * simds && waves % simds != 0) a.place_crowded = (int)(waves / simds) + 1;
+            // (from ONE wavefront per SIMD upward: 6 144 chains = 1.5 per SIMD 23.5 -> 21.0 ms, profiles/r03/shape_sweep.txt)
+            if (all_resident && waves > simds && waves % simds != 0) a.place_crowded = (int)(waves / simds) + 1;
             else {
                 a.place = nullptr;
                 // with a chain queue the order still serves: the queue hands the chains out longest first, four of similar
