@@ -851,7 +851,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
         }
         if (dbg.specg == 8 || dbg.specg == 16 || dbg.specg == 32 || dbg.specg == 64) sg = dbg.specg;
-        if (m->h.nq > sg * (sg == 8 ? 16 : 8) && sg < 32) sg = 32;  // no instantiation that wide at 8 / 16 lanes per role (stac_kernels.hip): four wavefronts per chain
+        // no instantiation wider than 10 registers per vector at 8 lanes per role, 8 at 16 (stac_kernels.hip): more lanes per role
+        if (sg == 8 && m->h.nq > 80) sg = 16;
+        if (sg == 16 && m->h.nq > 128) sg = 32;
         // roles per chain: four (two candidates + their momentum points, two chains per wavefront) once the batch is so
         // large that throughput counts, not the latency of one chain
         int sr = (sg == 8 && (long)nchains >= kSpec4MinChains) ? 4 : 8;
