@@ -6,6 +6,23 @@ import os, sys, traceback
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import pytest
 import test_gpu_parity as T
+
+if os.environ.get("STAC_FUZZ_POISON"):
+    # fill the scratch memory of every wavefront slot with 0xFFFFFFFF before every launch (tests/tools/poison_scratch.hip): a
+    # spill slot that is reloaded before it is stored then poisons the FIRST launch instead of depending on the previous one
+    import ctypes, subprocess, torch
+    from stac_mjx_amd import engine as _E
+    _so = os.path.join("build", "libpoison.so")
+    os.makedirs("build", exist_ok=True)
+    if not os.path.exists(_so):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-shared", "-fPIC", "tests/tools/poison_scratch.hip", "-o", _so], check=True)
+    _P = ctypes.CDLL(os.path.abspath(_so))
+    _P.poison_scratch.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    _orig = _E.Engine.q_phase
+    def _poisoned(self, *a, **k):
+        assert _P.poison_scratch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0xFFFFFFFF) == 0
+        return _orig(self, *a, **k)
+    _E.Engine.q_phase = _poisoned
 bad = 0; ran = 0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # `N big`: the large-tree / many-chain flavour (test_random_models_large_trees_many_chains)
 for seed in range(12, 12 + int(sys.argv[1])):
