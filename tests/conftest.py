@@ -21,6 +21,46 @@ REFERENCE = Path("/root/reference")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    _install_scratch_poison()
+
+
+def _install_scratch_poison():
+    """STAC_TEST_POISON=<hex pattern> (GPU box only): fill the scratch memory of every wavefront slot with the pattern before
+    every q_phase / q_solve launch of the suite (tests/tools/poison_scratch.hip, built on demand).  A kernel that reloads a
+    register spill slot before storing to it in the same launch then computes with the pattern instead of with what the
+    previous launch left behind -- the parity tests fail at once instead of by chance."""
+    import os
+
+    pat = os.environ.get("STAC_TEST_POISON")
+    if not pat:
+        return
+    import ctypes
+    import subprocess
+
+    import torch
+
+    from stac_mjx_amd import engine as eng_mod
+
+    so = ROOT / "build" / "libpoison.so"
+    so.parent.mkdir(exist_ok=True)
+    if not so.exists():
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-shared", "-fPIC",
+                        str(ROOT / "tests" / "tools" / "poison_scratch.hip"), "-o", str(so)], check=True)
+    lib = ctypes.CDLL(str(so))
+    lib.poison_scratch.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    value = int(pat, 16)
+
+    def wrap(name):
+        orig = getattr(eng_mod.Engine, name)
+
+        def poisoned(self, *a, **k):
+            assert lib.poison_scratch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), value) == 0
+            return orig(self, *a, **k)
+
+        setattr(eng_mod.Engine, name, poisoned)
+
+    for name in ("q_phase", "q_solve"):
+        wrap(name)
 
 
 @pytest.fixture(scope="session")
