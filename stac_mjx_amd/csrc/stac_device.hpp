@@ -187,7 +187,8 @@ __device__ __forceinline__ void st_tvec2(float *p, V3 v) { st_tpos(p + kXq, v); 
 // slide: the displacement).  This keeps the sincos off the serial chain of the FK that follows.  The result sits in
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
 // naj_lim: the leading joints to do (all, or -- root fast trips -- only the joints of the root passes' coordinates).
-__device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+template <class HT>
+__device__ __forceinline__ void joint_local_prepass(const HT &H, const float *P, float *CBc, const int lf, const int gf,
                                                     const int naj_lim, const int j_first = 0) {
     const float *jrec = P + H.off_joint;
     float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *ja = CBc + H.c_ja, *qsv = CBc + H.c_qsv;
@@ -227,7 +228,8 @@ __device__ __forceinline__ void joint_local_prepass(const PlanHeader &H, const f
 // A lane keeps the transform of the body it has just finished: the host lays the levels out so that a body sits
 // at its parent's position in the level wherever it can (flag bit 1), and then the parent transform never makes
 // the LDS round trip.  All lanes of the wavefront must call it together (wave-level synchronisation per level).
-__device__ __forceinline__ void fk_levels(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+template <class HT>
+__device__ __forceinline__ void fk_levels(const HT &H, const float *P, float *CBc, const int lf, const int gf,
                                           const bool active, const bool store_ja) {
     const int *lev_adr = reinterpret_cast<const int *>(P + H.off_lev_adr);
     const float *brec = P + H.off_body, *jrec = P + H.off_joint;
@@ -400,8 +402,8 @@ __device__ __forceinline__ void fk_step_uniform(const FkRegs &R, FkRegs &N, cons
     st_tquat(CBc + R.r1.z, quat);
     wave_sync();
 }
-template <int RW>
-__device__ __forceinline__ void fk_program(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+template <int RW, class HT>
+__device__ __forceinline__ void fk_program(const HT &H, const float *P, float *CBc, const int lf, const int gf,
                                            const bool active, const bool store_ja, const int prog_off, const int n_ml) {
     const int W = H.max_width;
     const bool on = active && lf < W;
@@ -690,8 +692,8 @@ __device__ __forceinline__ void fk_step_quad(const FkQuadRegs &R, FkQuadRegs &N,
     }
     wave_sync();
 }
-template <int RW, bool PSEL>
-__device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+template <int RW, bool PSEL, class HT>
+__device__ __forceinline__ void fk_program_quad(const HT &H, const float *P, float *CBc, const int lf, const int gf,
                                                 const bool active, const int prog_off, const int n_ml_even, const int n_run) {
     const int W = H.max_width;
     const int pp = lf >> 2, c = lf & 3;
@@ -763,8 +765,8 @@ __device__ __forceinline__ void fk_program_quad(const PlanHeader &H, const float
 // FK of one chain by gf lanes: the program when every level fits the lanes (four lanes per position when QUAD and
 // they fit four times over), else the level loop.
 // n_ml_root > 0 (wave-uniform): every chain of the wavefront is in a root pass -- run the pruned program at off_fkroot.
-template <bool QUAD, bool PSEL = false>
-__device__ __forceinline__ void fk_chain(const PlanHeader &H, const float *P, float *CBc, const int lf, const int gf,
+template <bool QUAD, bool PSEL = false, class HT>
+__device__ __forceinline__ void fk_chain(const HT &H, const float *P, float *CBc, const int lf, const int gf,
                                          const bool active, const bool store_ja, const bool use_levels,
                                          const int n_ml_root = 0, const int n_run_root = 0) {
     if (H.max_width <= gf && !use_levels) {

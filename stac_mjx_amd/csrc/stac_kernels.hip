@@ -57,7 +57,8 @@ namespace stac {
 // second trip with candidates 2 and 3): two chains per wavefront at 8 lanes per role, for large batches.
 template <int G, int NQR, int WPE, int SPEC>
 __global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void q_phase_kernel(const QArgs a) {
+void q_phase_kernel(const QArgs a_in) {
+    const QArgs &a = a_in;
     static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 32 || G == 64)) || (SPEC == 4 && (G == 8 || G == 16)), "speculative mode: 8 (or 4) roles of G lanes");
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
@@ -177,8 +178,8 @@ void q_phase_kernel(const QArgs a) {
     const int *hi = reinterpret_cast<const int *>(hs + 3 * nqpad);
     // (QArgs::perm: the launch's chains in the order the host wants them on the slots / in the queue)
     // queue position -> chain: with a queue the chains go out longest first (perm is ascending), the short ones fill the end
-    auto queue_chain = [&](const int pos) { return a.perm ? a.perm[(!SPEC && a.queue_slots > 0) ? a.C - 1 - pos : pos] : pos; };
-    int chain = a.resume ? (resuming ? hi[0] : a.C) : (slot_id < a.C && a.perm ? queue_chain(slot_id) : slot_id);  // with a chain queue
+    auto queue_chain = [&](const auto &a, const int pos) { return a.perm ? a.perm[(!SPEC && a.queue_slots > 0) ? a.C - 1 - pos : pos] : pos; };
+    int chain = a.resume ? (resuming ? hi[0] : a.C) : (slot_id < a.C && a.perm ? queue_chain(a, slot_id) : slot_id);  // with a chain queue
                                                                  // (QArgs::queue_slots) a group takes further chains when it has finished one
     int st = chain < a.C ? ST_VG_Y : ST_DONE;
     int kind = a.single ? 0 : (a.do_root_opt ? 0 : 2);  // index into the mask table
@@ -218,8 +219,14 @@ void q_phase_kernel(const QArgs a) {
     // initial qpos, keypoints of frame 0, first solve
     size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
     // keypoints of a frame: this lane's sites into registers, or the whole frame into LDS
-    auto load_kp = [&](const size_t base) {
-        if (site_regs) {
+    // (TripCtx: what the chain-level helpers below need of the launch and the lane, handed in by the caller, so that nothing
+    //  they use has to stay live across the trip loop: see "Launch arguments inside the trip loop" below)
+    struct TripCtx { int lg, nq, K; float *kpl; const float *lbv, *ubv, *qpos0; };
+    const TripCtx cx0{lg, nq, K, kpl, lbv, ubv, qpos0};
+    auto load_kp = [&](const auto &a, const TripCtx &cx, const size_t base) {
+        const int lg = cx.lg, K = cx.K;
+        float *const kpl = cx.kpl;
+        if (K <= NSR * G) {
 #pragma unroll
             for (int r = 0; r < NSR; ++r) {
                 const int k = r * G + lg;
@@ -237,7 +244,7 @@ void q_phase_kernel(const QArgs a) {
         q0[r] = v;
     }
     if (st != ST_DONE) {
-        load_kp(kp_chain + (size_t)frame * 3 * K);
+        load_kp(a, cx0, kp_chain + (size_t)frame * 3 * K);
         if (!a.single && kind < 2 && !resuming) {  // root pass: q0[:3] = keypoint of the root marker (compute_stac.py:57-59)
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -254,7 +261,9 @@ void q_phase_kernel(const QArgs a) {
     // they drop out of every norm and never move, and the solver transition of a root fast trip looks at register 0 only.
     // (They are constant over a chain's root solves, so this is settled when the chain starts.)
     bool tail_ok = true;
-    auto check_tail = [&]() {
+    auto check_tail = [&](const auto &a, const TripCtx &cx) {
+        const int lg = cx.lg, nq = cx.nq;
+        const float *const lbv = cx.lbv, *const ubv = cx.ubv;
         tail_ok = true;
 #pragma unroll
         for (int r = 0; r < NQR; ++r) {
@@ -262,9 +271,11 @@ void q_phase_kernel(const QArgs a) {
             if (e < nq && e >= a.root_fast && !(q0[r] >= lbv[e] && q0[r] <= ubv[e])) tail_ok = false;
         }
     };
-    if (!SPEC && a.root_fast > 0) check_tail();
+    if (!SPEC && a.root_fast > 0) check_tail(a, cx0);
     // the same for the next chain a group takes from the queue (all lanes of the group call it together)
-    auto begin_chain = [&](const int c) {
+    auto begin_chain = [&](const auto &a, const TripCtx &cx, const int c) {
+        const int lg = cx.lg, nq = cx.nq, K = cx.K;
+        const float *const qpos0 = cx.qpos0;
         chain = c;
         kp_chain = (size_t)c * a.F * 3 * K;
         kind = a.do_root_opt ? 0 : 2;
@@ -279,10 +290,10 @@ void q_phase_kernel(const QArgs a) {
             if (kind < 2 && e < 3) v = a.kp[kp_chain + 3 * a.root_kp_idx + e];
             q0[r] = v; x[r] = v; y[r] = v; g[r] = 0.f;
         }
-        load_kp(kp_chain);
+        load_kp(a, cx, kp_chain);
         st = ST_VG_Y;
         ql_fresh = false;
-        if (!SPEC && a.root_fast > 0) check_tail();
+        if (!SPEC && a.root_fast > 0) check_tail(a, cx);
     };
     if (resuming) {
 #pragma unroll
@@ -315,22 +326,47 @@ void q_phase_kernel(const QArgs a) {
     PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
     const int lg_outer = lg;
+    // Launch arguments inside the trip loop.  QArgs is 424 bytes of kernel argument: read once in the prologue, every field
+    // -- and every address or lane mask derived from one -- stays live across the whole trip loop, and the kernel ran with 190
+    // to 310 scalars spilled into vector-register lanes (v_readlane at every use: a tenth of its vector instructions) on top of
+    // which the vector registers themselves spilled to scratch.  So the loop reads what it needs from the kernarg segment again,
+    // where it needs it (scalar loads through `a`, below; the constant cache holds the segment): throughput kernels through a
+    // pointer that is made opaque once per trip, so that no load can be hoisted out of the loop; latency kernels (a lone
+    // wavefront per SIMD has nothing to hide a scalar load behind) leave the choice to the compiler and launder only the
+    // pointer of the cold end-of-solve block.  Measured (10 000-frame bench / 40 x 250 clips): +3.5 % / -1.5 %; SGPR spills of the
+    // shipped instantiations 103-313 -> 0-35, the headline kernel from 19 spilled VGPRs to none at 154 of 168.
+    typedef const __attribute__((address_space(4))) QArgs KQArgs;
+    KQArgs *const ak_base = (KQArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr bool kReloadPerTrip = SPEC == 0;
     const int cb_words = (int)(CB - lds);
     while (__any(st != ST_DONE)) {
         PROF_TICK(0);  // loop control
         PROF_TRIP;
-        // Opaque per trip (168-VGPR build): every address that depends on the lane or on the chain's region is recomputed
-        // inside the trip (one VALU add each) instead of being hoisted out of the loop, where four dozen of them lived for
-        // the whole launch and were spilled: 192 -> 16 B of scratch per lane, 52 -> 12 MB of HBM traffic per 10 000-frame
-        // step, at 1.8 % of the frame rate (the reloads overlapped better than the adds do).  The 128-VGPR build spills
-        // either way and keeps the hoisted form.
+        KQArgs *ak_t = ak_base;
+        if constexpr (kReloadPerTrip) asm volatile("" : "+s"(ak_t));
+        KQArgs &a = *ak_t;
+        const auto &H = a.h;
+        // ... and neither does anything derived from it: the names below shadow the prologue's
+        const int nq = H.nq, K = H.K, nqpad = H.nqpad;
+        const int plan_words = (H.total_words - H.plan_skip + 3) & ~3;
+        uint32_t *const MB = reinterpret_cast<uint32_t *>(lds + plan_words);
+        const int nkinds = a.single ? 1 : a.P + 3;
+        const int hstride = 3 * nqpad + 12;
+        const bool site_regs = K <= NSR * G;
+        const float *const jrec = P + H.off_joint, *const srec = P + H.off_site;
+        const float *const lbv = P + H.off_lb, *const ubv = P + H.off_ub;
+        const int *const quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
+        // The lane index and the chain's region likewise: opaque per trip, so that every address and every lane mask that
+        // depends on them is recomputed inside the trip (one VALU instruction each) instead of being hoisted out of the loop,
+        // where dozens of them lived for the whole launch and were spilled.
         int lg_t = lg_outer, cb_t = cb_words;
-        if constexpr (SPEC == 0 && WPE == 3) asm volatile("" : "+v"(lg_t), "+v"(cb_t));
+        asm volatile("" : "+v"(lg_t), "+v"(cb_t));
         const int lg = lg_t;
         float *const CB = lds + cb_t;
         float *const bx = CB + H.c_bx, *const ja = CB + H.c_ja, *const jn = CB + H.c_jn, *const qsv = CB + H.c_qsv;
         float *const sw = CB + H.c_sw, *const gg = sw, *const r2 = CB + H.c_r2;
         float *const qe = sw, *const kpl = CB + H.c_kp;
+        const TripCtx cx{lg, nq, K, kpl, lbv, ubv, P + H.off_qpos0};
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
@@ -379,7 +415,7 @@ void q_phase_kernel(const QArgs a) {
                         int nxt = 0;
                         if (lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
                         nxt = __shfl(nxt, grp * G, 64);
-                        if (nxt < a.C) begin_chain(queue_chain(nxt));
+                        if (nxt < a.C) begin_chain(a, cx, queue_chain(a, nxt));
                         else st = ST_DONE;
                     }
                     if (!__any(st != ST_DONE)) break;
@@ -1046,6 +1082,14 @@ void q_phase_kernel(const QArgs a) {
         PROF_TICK(8);  // accept / fused residual
         // ---- end of a solve: replace_qs (utils.py:147-169), next solve / next frame ------------------------
         if (__any(ending)) {
+            // (cold: once per solve.  What it needs of the launch is read here, whatever the trip keeps in registers)
+            KQArgs *ak_c = ak_base;
+            asm volatile("" : "+s"(ak_c));
+            KQArgs &a = *ak_c;
+            const auto &H = a.h;
+            const int nq = H.nq, K = H.K;
+            const int *const quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
+            const TripCtx cx{lg, nq, K, CB + H.c_kp, P + H.off_lb, P + H.off_ub, P + H.off_qpos0};
             if (ending) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
@@ -1128,11 +1172,11 @@ void q_phase_kernel(const QArgs a) {
                                         if (SPEC ? (lane % LC) == 0 : lg == 0) nxt = atomicAdd(a.ctl + 4, 1);
                                         nxt = __shfl(nxt, SPEC ? (lane / LC) * LC : grp * G, 64);
                                     }
-                                    if (nxt < a.C) begin_chain(queue_chain(nxt));
+                                    if (nxt < a.C) begin_chain(a, cx, queue_chain(a, nxt));
                                 }
                             }
                         } else {
-                            load_kp(kp_chain + (size_t)frame * 3 * K);
+                            load_kp(a, cx, kp_chain + (size_t)frame * 3 * K);
                         }
                     } else if (kind < 2) {  // second root pass: seed the translation again (compute_stac.py:80-81)
 #pragma unroll
@@ -1147,7 +1191,7 @@ void q_phase_kernel(const QArgs a) {
                         stepsize = 1.0f; t = 1.0f; iter = 0;
                         error = __builtin_inff();
                         st = ST_VG_Y;
-                        if (!SPEC && a.root_fast > 0 && kind < 2) check_tail();  // the next root solve starts from q0 again
+                        if (!SPEC && a.root_fast > 0 && kind < 2) check_tail(a, cx);  // the next root solve starts from q0 again
                         // root solves over: the pose solves begin when the wavefront's other chains are there too (top of the loop)
                         if (!SPEC && a.root_fast > 0 && was_root && kind == 2) st = ST_WAIT;
                     }
@@ -1397,11 +1441,16 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
         // with unrelated changes (round 3: first the 16- and 32-register shapes at 16 / 32 lanes, then, with another
         // instruction scheduling strategy, the 16-register shape at 8 lanes; tests/test_gpu_parity.py::_q_phase_twice and
         // tests/fuzz_random_models.py catch it).  Wider models take more lanes per role instead (host: run_q).
+#ifdef STAC_INST_SUBSET  // developer builds (experiments): only the shapes of the default bench and of its 250-frame-clip leg
+        STAC_TRY_SPEC(16, 5, 2, 4)
+        STAC_TRY_SPEC(32, 3, 2, 8)
+#else
         STAC_TRY_SPEC(8, 10, 2, 4)
         STAC_TRY_SPEC(8, 10, 2, 8)
         STAC_TRY_SPEC(16, 5, 2, 4) STAC_TRY_SPEC(16, 8, 2, 4)
         STAC_TRY_SPEC(32, 3, 2, 8) STAC_TRY_SPEC(32, 8, 2, 8)
         STAC_TRY_SPEC(64, 2, 2, 8) STAC_TRY_SPEC(64, 4, 2, 8)
+#endif
 #undef STAC_TRY_SPEC
         return hipErrorInvalidValue;
     }
@@ -1414,11 +1463,15 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
         return wpe >= 4 ? launch_q<GG, RR, 4, 0>(a, wpb, lds_bytes, s)            \
                         : launch_q<GG, RR, 2, 0>(a, wpb, lds_bytes, s);           \
     }
+#ifdef STAC_INST_SUBSET
+    STAC_TRY(16, 5)
+#else
     STAC_TRY(4, 20) STAC_TRY(4, 32)
     STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)
     STAC_TRY(16, 5) STAC_TRY(16, 8) STAC_TRY(16, 16)
     STAC_TRY(32, 3) STAC_TRY(32, 4) STAC_TRY(32, 8)
     STAC_TRY(64, 2) STAC_TRY(64, 4)
+#endif
 #undef STAC_TRY
     return hipErrorInvalidValue;
 }
