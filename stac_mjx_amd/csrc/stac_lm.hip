@@ -133,8 +133,42 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
     wave_sync();
 
     PROF_DECL;
+    // Launch arguments inside the trip loop: read from the kernarg segment again in every trip, through a pointer that is
+    // opaque per trip, together with everything derived from them and from the lane index (stac_kernels.hip, q_phase_kernel:
+    // "Launch arguments inside the trip loop"): nothing of QArgs / LmArgs stays live across the loop, where it used to
+    // cost 103-152 scalars spilled into vector-register lanes and up to 308 B of scratch per lane.
+    struct LmKernArgs { QArgs a; LmArgs L; };
+    static_assert(offsetof(LmKernArgs, L) == sizeof(QArgs), "kernarg layout: LmArgs follows QArgs without padding");
+    typedef const __attribute__((address_space(4))) LmKernArgs KArgs;
+    KArgs *const ak_base = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lg_outer = lg, cb_words = (int)(CB - lds);
     while (__any(st != LM_DONE)) {
         PROF_TICK(0);
+        KArgs *ak_t = ak_base;
+        asm volatile("" : "+s"(ak_t));
+        const auto &a = ak_t->a;
+        const auto &L = ak_t->L;
+        const auto &H = a.h;
+        int lg_t = lg_outer, cb_t = cb_words;
+        asm volatile("" : "+v"(lg_t), "+v"(cb_t));
+        const int lg = lg_t;
+        // (the names below shadow the prologue's)
+        const int nq = H.nq, K = H.K, nqpad = H.nqpad;
+        const int plan_words = (H.total_words + 3) & ~3;
+        uint32_t *const MB = reinterpret_cast<uint32_t *>(lds + plan_words);
+        const int nkinds = a.P + 3;
+        int *const KH = reinterpret_cast<int *>(lds + plan_words + a.mb_words);
+        int *const KT = KH + ((nkinds * kLmKindWords + 3) & ~3);
+        int *const TRI = KT + ((L.hot_words + 3) & ~3);
+        float *const CB = lds + cb_t;
+        float *const bx = CB + H.c_bx, *const ja = CB + H.c_ja, *const jn = CB + H.c_jn;
+        float *const sw = CB + H.c_sw, *const gg = CB + H.c_gg, *const r2 = CB + H.c_gg;
+        float *const qe = CB + H.c_qe, *const kpl = CB + H.c_kp;
+        float *const sxs = CB + L.c_sx, *const Jp = CB + L.c_jp, *const Hc = CB + L.c_jp, *const Ap = CB + L.c_A;
+        float *const bv = CB + L.c_b, *const dv = CB + L.c_d, *const fz = CB + L.c_fz;
+        const float *const jrec = P + H.off_joint, *const srec = P + H.off_site;
+        const float *const lbv = P + H.off_lb, *const ubv = P + H.off_ub, *const qpos0 = P + H.off_qpos0;
+        const int *const quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
         const int st_in = st;
         const uint32_t mbits = MB[kind * G + lg], dbits = MB[nkinds * G + kind * G + lg];
         const LmKind kh = *reinterpret_cast<const LmKind *>(KH + kLmKindWords * kind);
