@@ -77,7 +77,8 @@ typedef struct stac_q_params {
     float tol;               /* FTOL: stop when ||clip(x - grad) - x||_2 <= tol */
     int32_t maxiter;         /* N_ITER_Q (>= 1) */
     int32_t maxls;           /* line-search halvings, jaxopt default 15 */
-    int32_t lanes_per_chain; /* 0 = auto; else 4, 8, 16, 32 or 64 lanes of a wavefront per chain */
+    int32_t lanes_per_chain; /* 0 = auto; else 8, 16, 32 or 64 lanes of a wavefront per chain (a width that is not built for
+                                this model -- 4 always -- runs on the next wider one; results do not depend on it) */
     int32_t solver;          /* STAC_SOLVER_PG (the reference's algorithm, parity mode) or STAC_SOLVER_LM */
     float lm_lambda0;        /* LM only: initial damping (0 -> 1e-2); maxiter then counts accepted LM steps */
 } stac_q_params;

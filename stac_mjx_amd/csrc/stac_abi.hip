@@ -16,6 +16,7 @@
 #include "stac_plan.hpp"
 
 namespace stac {
+bool q_phase_has_variant(int G, int nq, int wpe);
 hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
                           int *capacity_out);
 hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
@@ -601,7 +602,7 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_need
     constexpr size_t kGranule = 1280;
     QShape best{0, 2, 0};
     for (int wpe = 2; wpe <= 4; ++wpe) {
-        if (wpe == 3 && G != 16) continue;  // the 168-VGPR variant (one 10-wave workgroup per CU) exists for 16-lane groups
+        if (!q_phase_has_variant(G, h.nq, wpe)) continue;  // (stac_kernels.hip, STAC_Q_SHAPES: only shapes that pass the spill gate are built)
         for (int wpb = 1; wpb <= (wpe == 3 ? 10 : 8); ++wpb) {
             size_t lds = q_lds_bytes(h, G, nkinds, wpb);
             if (lds > kLdsPerCu) break;

@@ -1423,55 +1423,60 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
     return hipGetLastError();
 }
 
-// nq capacity of an instantiation is G*NQR.  wpb = wavefronts per workgroup (they share the plan copy),
-// wpe = 2 or 4 (register cap variant), spec = latency mode (G must be 8).
+// ---- the instantiations that ship -------------------------------------------------------------------------------------------
+// (lanes per chain G, solver registers per lane NQR: nq <= G * NQR, register cap WPE).  Every shape here passes the resource
+// gate of tests/test_isa_hazards.py (scratch <= 64 B per lane, <= 40 scalars spilled into vector lanes; table:
+// profiles/r04/resource_usage.txt).  What does not is not built: the 128-VGPR variants of the 8- and 16-lane kernels (74 to 750
+// spilled vector registers), 32 solver registers per lane at 4 or 8 lanes and the 4-lane kernels altogether (160 B to 1.3 KB of
+// scratch; never chosen automatically, slower than 16 lanes at every batch size) -- a request for them runs on the next wider
+// group, results are the same bit for bit.  Latency kernels stop at 10 solver registers per lane at 8 lanes and 8 at 16 or 32
+// (round 3: the wider ones, 300+ B of scratch, read spill slots before writing them); wider models take more lanes per role.
+#ifdef STAC_INST_SUBSET  // developer builds (experiments): only the shapes of the default bench and of its 250-frame-clip leg
+#define STAC_Q_SHAPES(X) X(16, 5, 2) X(16, 5, 3)
+#define STAC_Q_SPEC_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
+#else
+#define STAC_Q_SHAPES(X)                                                        \
+    X(8, 10, 2) X(8, 16, 2)                                                      \
+    X(16, 5, 2) X(16, 5, 3) X(16, 8, 2) X(16, 8, 3) X(16, 16, 2)                 \
+    X(32, 3, 2) X(32, 3, 4) X(32, 4, 2) X(32, 4, 4) X(32, 8, 2)                  \
+    X(64, 2, 2) X(64, 2, 4) X(64, 4, 2) X(64, 4, 4)
+// (G lanes per role, NQR, roles per chain)
+#define STAC_Q_SPEC_SHAPES(X)                                                   \
+    X(8, 10, 4) X(8, 10, 8) X(16, 5, 4) X(16, 8, 4) X(32, 3, 8) X(32, 8, 8) X(64, 2, 8) X(64, 4, 8)
+#endif
+
+// Is there a throughput instantiation with G lanes per chain and register cap wpe that holds nq coordinates?
+bool q_phase_has_variant(int G, int nq, int wpe) {
+#define STAC_HAS(GG, RR, WW) if (G == GG && wpe == WW && nq <= GG * RR) return true;
+    STAC_Q_SHAPES(STAC_HAS)
+#undef STAC_HAS
+    return false;
+}
+
+// wpb = wavefronts per workgroup (they share the plan copy), wpe = register-cap variant (2, 3 or 4 wavefronts per SIMD; the
+// nearest one that exists for G is taken), spec = evaluation roles per chain in latency mode (0 = throughput mode).
+// *capacity_out = G * NQR of the instantiation that ran, 0 if none holds nq at this G.
 hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
                           int *capacity_out) {
     const int nq = a.h.nq;
     *capacity_out = 0;
     if (spec) {
-#define STAC_TRY_SPEC(GG, RR, WW, NRR)                               \
-    if (G == GG && spec == NRR && nq <= GG * RR) {                   \
-        *capacity_out = GG * RR;                                     \
-        return launch_q<GG, RR, WW, NRR>(a, wpb, lds_bytes, s);      \
+#define STAC_TRY_SPEC(GG, RR, NRR)                                  \
+    if (G == GG && spec == NRR && nq <= GG * RR) {                  \
+        *capacity_out = GG * RR;                                    \
+        return launch_q<GG, RR, 2, NRR>(a, wpb, lds_bytes, s);      \
     }
-        // Latency-kernel instantiations stop at 10 solver registers per lane at 8 lanes and 8 at 16 or 32: the wider ones (16 or
-        // 32 registers per vector, six vectors: 300+ bytes of scratch per lane) turned out to depend on what the previous
-        // launch left behind -- a value reloaded from a spill slot before it is stored, moving from one shape to the other
-        // with unrelated changes (round 3: first the 16- and 32-register shapes at 16 / 32 lanes, then, with another
-        // instruction scheduling strategy, the 16-register shape at 8 lanes; tests/test_gpu_parity.py::_q_phase_twice and
-        // tests/fuzz_random_models.py catch it).  Wider models take more lanes per role instead (host: run_q).
-#ifdef STAC_INST_SUBSET  // developer builds (experiments): only the shapes of the default bench and of its 250-frame-clip leg
-        STAC_TRY_SPEC(16, 5, 2, 4)
-        STAC_TRY_SPEC(32, 3, 2, 8)
-#else
-        STAC_TRY_SPEC(8, 10, 2, 4)
-        STAC_TRY_SPEC(8, 10, 2, 8)
-        STAC_TRY_SPEC(16, 5, 2, 4) STAC_TRY_SPEC(16, 8, 2, 4)
-        STAC_TRY_SPEC(32, 3, 2, 8) STAC_TRY_SPEC(32, 8, 2, 8)
-        STAC_TRY_SPEC(64, 2, 2, 8) STAC_TRY_SPEC(64, 4, 2, 8)
-#endif
+        STAC_Q_SPEC_SHAPES(STAC_TRY_SPEC)
 #undef STAC_TRY_SPEC
         return hipErrorInvalidValue;
     }
-#define STAC_TRY(GG, RR)                                                          \
-    if (G == GG && nq <= GG * RR) {                                               \
-        *capacity_out = GG * RR;                                                  \
-        if constexpr (GG == 16) {                                                 \
-            if (wpe == 3) return launch_q<GG, RR, 3, 0>(a, wpb, lds_bytes, s);     \
-        }                                                                         \
-        return wpe >= 4 ? launch_q<GG, RR, 4, 0>(a, wpb, lds_bytes, s)            \
-                        : launch_q<GG, RR, 2, 0>(a, wpb, lds_bytes, s);           \
+    if (!q_phase_has_variant(G, nq, wpe)) wpe = 2;  // (every G has its 2-per-SIMD variants)
+#define STAC_TRY(GG, RR, WW)                                        \
+    if (G == GG && wpe == WW && nq <= GG * RR) {                    \
+        *capacity_out = GG * RR;                                    \
+        return launch_q<GG, RR, WW, 0>(a, wpb, lds_bytes, s);       \
     }
-#ifdef STAC_INST_SUBSET
-    STAC_TRY(16, 5)
-#else
-    STAC_TRY(4, 20) STAC_TRY(4, 32)
-    STAC_TRY(8, 10) STAC_TRY(8, 16) STAC_TRY(8, 32)
-    STAC_TRY(16, 5) STAC_TRY(16, 8) STAC_TRY(16, 16)
-    STAC_TRY(32, 3) STAC_TRY(32, 4) STAC_TRY(32, 8)
-    STAC_TRY(64, 2) STAC_TRY(64, 4)
-#endif
+    STAC_Q_SHAPES(STAC_TRY)
 #undef STAC_TRY
     return hipErrorInvalidValue;
 }

@@ -181,7 +181,7 @@ def test_q_phase_missing_keypoints_terminate_and_stay_in_their_chain(rodent_setu
 
 
 @pytest.mark.parametrize("flags", ["0", "2", "4"])
-@pytest.mark.parametrize("lanes", [4, 16, 32])
+@pytest.mark.parametrize("lanes", [8, 16, 32])
 def test_q_phase_fk_program_and_level_loop_agree(rodent_setup, fly_setup, rodent_mocap, monkeypatch, flags, lanes):
     """The kernel has several FK implementations: the step program (one lane or four lanes per position; as ONE
     straight-line step when the model allows it, else -- or with STAC_HIP_FLAGS bit 2 -- step by step through flags and
@@ -225,10 +225,11 @@ def test_q_phase_fk_implementations_agree_on_the_mouse(mouse_setup, monkeypatch,
                                      do_root_opt=ms.do_root_opt))
 
 
-@pytest.mark.parametrize("wpe,wpb", [("2", "3"), ("3", "10"), ("4", "5"), ("4", "8")])
+@pytest.mark.parametrize("wpe,wpb", [("2", "3"), ("3", "10"), ("2", "8"), ("4", "5")])
 def test_q_phase_register_cap_variants(rodent_setup, rodent_mocap, monkeypatch, wpe, wpb):
-    """The 256- / 168- / 128-VGPR builds of the 16-lane kernel (the launch shapes of large batches, forced here on a
-    small one through the developer overrides), multi-wave workgroups with ragged last blocks: all equal the oracle."""
+    """The 2- and 3-wavefronts-per-SIMD builds of the 16-lane kernel (the launch shapes of large batches, forced here on a
+    small one through the developer overrides), multi-wave workgroups with ragged last blocks: all equal the oracle.  (There
+    is no 128-VGPR build at 16 lanes any more -- it did not pass the spill gate: a request for it runs the 2-per-SIMD one.)"""
     monkeypatch.setenv("STAC_HIP_WPE", wpe)
     monkeypatch.setenv("STAC_HIP_WPB", wpb)
     fs = rodent_setup
@@ -712,7 +713,7 @@ def test_random_models_bit_exact(seed):
     trunk[0] = 1
     do_root = free_root
     ref = orc.ik_clips(kp, lb, ub, part, trunk, 0, 7, do_root_opt=do_root)
-    for lanes in (4, 16, 0):
+    for lanes in (8, 16, 0):
         eng = Engine(t, lb, ub, tol=1e-5, maxiter=12, lanes_per_chain=lanes)
         fk = eng.fk(q)
         for i in range(len(q)):
@@ -974,3 +975,115 @@ def test_chain_order_and_placement_by_simd_load(rodent_setup, rodent_mocap, monk
     for i, c in enumerate(sel):
         np.testing.assert_array_equal(_np(a["qpos"][c]), ref["qpos"][i])
         np.testing.assert_array_equal(_np(a["counters"][c]).astype(np.uint32), ref["counters"][i])
+
+
+# ---- round 4: every shipped instantiation, twice -------------------------------------------------------------------------------
+# stac_kernels.hip, STAC_Q_SHAPES / STAC_Q_SPEC_SHAPES and stac_lm.hip: (lanes, registers per lane, register cap / roles).  Each
+# case forces one instantiation through the developer switches, launches it twice on the same engine and compares with the
+# oracle (PG: bit for bit; LM: finite, repeatable, inside the box, marker error no worse than the PG answer).  The list of
+# kernels this suite launches on a GPU is committed as profiles/r04/gpu_suite_kernels.txt; tests/test_isa_hazards.py checks on
+# the CPU that every q_phase instantiation of the built library is in it.
+def _mid_model():
+    """A random tree with nq = 119 (free root, hinges and slides): the 16-registers-at-8-lanes, 8-at-16 and 4-at-32 shapes."""
+    from stac_mjx_amd.mjcf import JNT_FREE
+
+    rng = np.random.default_rng(5000)
+    t = _random_tables(rng, 90, True, p_ball=0.0, max_children_bias=0.6)
+    assert t.nq == 119
+    lb, ub = np.full(t.nq, -np.inf, np.float32), np.full(t.nq, np.inf, np.float32)
+    for j in range(t.njnt):
+        a, ty = int(t.jnt_qposadr[j]), int(t.jnt_type[j])
+        if ty == JNT_FREE:
+            lb[a + 3:a + 7], ub[a + 3:a + 7] = -1, 1
+        else:
+            lb[a], ub[a] = min(t.jnt_range[j, 0], 0.0), t.jnt_range[j, 1]
+    part = np.zeros((2, t.nq), np.uint8)
+    part[0] = rng.random(t.nq) < 0.3
+    part[1] = rng.random(t.nq) < 0.15
+    trunk = (rng.random(t.nsite) < 0.6).astype(np.uint8)
+    trunk[0] = 1
+    return t, lb, ub, part, trunk, rng
+
+
+_SHAPE_CASES = [
+    # (model, lanes, solver, environment)                                       instantiation
+    ("rodent", 8, "pg", {}),                                                    # q<8,10,2,0>
+    ("rodent", 16, "pg", {"STAC_HIP_WPE": "2"}),                                # q<16,5,2,0>
+    ("rodent", 16, "pg", {"STAC_HIP_WPE": "3"}),                                # q<16,5,3,0>
+    ("rodent", 32, "pg", {"STAC_HIP_WPE": "2"}),                                # q<32,3,2,0>
+    ("rodent", 32, "pg", {"STAC_HIP_WPE": "4"}),                                # q<32,3,4,0>
+    ("rodent", 64, "pg", {"STAC_HIP_WPE": "2"}),                                # q<64,2,2,0>
+    ("rodent", 64, "pg", {"STAC_HIP_WPE": "4"}),                                # q<64,2,4,0>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "8", "STAC_HIP_SPECR": "4"}),   # q<8,10,2,4>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "8"}),         # q<8,10,2,8>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),        # q<16,5,2,4>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),        # q<32,3,2,8>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "64"}),        # q<64,2,2,8>
+    ("mid", 8, "pg", {}),                                                       # q<8,16,2,0>
+    ("mid", 16, "pg", {"STAC_HIP_WPE": "2"}),                                   # q<16,8,2,0>
+    ("mid", 16, "pg", {"STAC_HIP_WPE": "3"}),                                   # q<16,8,3,0>
+    ("mid", 32, "pg", {"STAC_HIP_WPE": "2"}),                                   # q<32,4,2,0>
+    ("mid", 32, "pg", {"STAC_HIP_WPE": "4"}),                                   # q<32,4,4,0>
+    ("mid", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),           # q<16,8,2,4>
+    ("mouse", 16, "pg", {}),                                                    # q<16,16,2,0>
+    ("mouse", 32, "pg", {}),                                                    # q<32,8,2,0>
+    ("mouse", 64, "pg", {"STAC_HIP_WPE": "2"}),                                 # q<64,4,2,0>
+    ("mouse", 64, "pg", {"STAC_HIP_WPE": "4"}),                                 # q<64,4,4,0>
+    ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),         # q<32,8,2,8>
+    ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "64"}),         # q<64,4,2,8>
+    ("rodent", 16, "lm", {}), ("rodent", 32, "lm", {}), ("rodent", 64, "lm", {}),     # lm<16,5,2> lm<32,3,2> lm<64,2,3>
+    ("mid", 16, "lm", {}),                                                      # lm<16,8,2>
+    ("mouse", 16, "lm", {}), ("mouse", 32, "lm", {}), ("mouse", 64, "lm", {}),   # lm<16,16,2> lm<32,8,2> lm<64,4,2>
+]
+
+
+@pytest.mark.parametrize("model,lanes,solver,env", _SHAPE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else
+                         "-".join(f"{k[9:]}{x}" for k, x in v.items()) or "auto")
+def test_every_shipped_instantiation_twice(rodent_setup, mouse_setup, rodent_mocap, monkeypatch, model, lanes, solver, env):
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    maxiter = 14
+    if model == "mid":
+        t, lb, ub, part, trunk, rng = _mid_model()
+        orc = Oracle(t, tol=1e-5, maxiter=maxiter)
+        q = np.tile(t.qpos0, (10, 1)) + rng.normal(0, 0.15, (10, t.nq)).astype(np.float32)
+        q = np.clip(q, np.where(np.isfinite(lb), lb, -3), np.where(np.isfinite(ub), ub, 3)).astype(np.float32)
+        kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32)
+        kp = (kp + rng.normal(0, 2e-3, kp.shape)).astype(np.float32).reshape(5, 2, 3 * t.nsite)
+        kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=True)
+        okw = dict(do_root_opt=True)
+        tol = 1e-5
+    else:
+        fs = rodent_setup if model == "rodent" else mouse_setup
+        t, lb, ub, part, trunk, tol = fs.tables, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 1e-4
+        orc = Oracle(t, tol=tol, maxiter=maxiter)
+        if model == "rodent":
+            kp = rodent_mocap[300:310].reshape(5, 2, 69)
+            do_root = True
+        else:
+            rng = np.random.default_rng(77)
+            qm = t.qpos0[None] + np.clip(rng.normal(0, 0.05, (6, t.nq)), -0.1, 0.1).astype(np.float32)
+            qm[:, 3:7] = t.qpos0[3:7]
+            kp = np.stack([orc.fk(x)["site_xpos"].reshape(-1) for x in qm]).reshape(3, 2, 3 * t.nsite).astype(np.float32)
+            do_root = fs.do_root_opt
+        kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=do_root)
+        okw = dict(do_root_opt=do_root)
+    rk, rd = kw["root_kp_idx"], kw["root_dims"]
+    if solver == "pg":
+        eng = Engine(t, lb, ub, tol=tol, maxiter=maxiter, lanes_per_chain=lanes)
+        res = _q_phase_twice(eng, kp, **kw)
+        _compare_phase(res, orc.ik_clips(kp, lb, ub, part, trunk, rk, rd, **okw))
+    else:
+        eng = Engine(t, lb, ub, tol=tol, solver="lm", lm_maxiter=8, lanes_per_chain=lanes)
+        a, b = eng.q_phase(kp, **kw), eng.q_phase(kp, **kw)
+        for k in ("qpos", "frame_error", "counters", "marker_sites"):
+            assert (a[k] == b[k]).all(), k
+        qo, mk = _np(a["qpos"]), _np(a["marker_sites"])
+        assert np.isfinite(qo).all() and (qo >= lb - 1e-6).all() and (qo <= ub + 1e-6).all()
+        pg = orc.ik_clips(kp, lb, ub, part, trunk, rk, rd, **okw)
+        tgt = kp.reshape(mk.shape)
+        assert np.linalg.norm(mk - tgt, axis=-1).mean() <= np.linalg.norm(pg["marker_sites"] - tgt, axis=-1).mean() + 1e-4
+    eng.close()

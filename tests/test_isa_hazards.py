@@ -16,34 +16,32 @@ import pytest
 
 from conftest import ROOT
 
-LLVM = Path("/opt/rocm/lib/llvm/bin")
 LIB = ROOT / "stac_mjx_amd" / "csrc" / "libstac_hip.so"
-MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _built_library():
+    from stac_mjx_amd import resource_usage as ru
+    from stac_mjx_amd.build import build_extension
+
+    if not ru.tools_available():
+        pytest.skip("binutils / ROCm LLVM tools not available")
+    build_extension()
+    return ru
 
 
 def _disassemble(tmp_path):
-    objcopy = shutil.which("objcopy")
-    bundler, objdump = LLVM / "clang-offload-bundler", LLVM / "llvm-objdump"
-    if not (objcopy and bundler.exists() and objdump.exists()):
-        pytest.skip("binutils / ROCm LLVM tools not available")
-    from stac_mjx_amd.build import build_extension
-
-    build_extension()
-    fat = tmp_path / "fat.bin"
-    subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", str(LIB), str(fat)], check=True)
-    blob = fat.read_bytes()
-    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
-    assert starts, "no offload bundle in the library"
+    """-> one llvm-objdump text per translation unit of the library"""
+    ru = _built_library()
     texts = []
-    for i, a in enumerate(starts):  # one bundle per translation unit
-        chunk = tmp_path / f"bundle{i}.bin"
-        chunk.write_bytes(blob[a:(starts[i + 1] if i + 1 < len(starts) else len(blob))])
-        co = tmp_path / f"dev{i}.co"
-        subprocess.run([str(bundler), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                        f"--input={chunk}", f"--output={co}"], check=True, capture_output=True)
-        out = subprocess.run([str(objdump), "-d", "--mcpu=gfx950", str(co)], check=True, capture_output=True, text=True).stdout
-        texts.append(out)
+    for co in ru.code_objects(LIB, tmp_path):
+        texts.append(subprocess.run([str(ru.LLVM / "llvm-objdump"), "-d", "--mcpu=gfx950", str(co)], check=True, capture_output=True, text=True).stdout)
     return texts
+
+
+@pytest.fixture(scope="module")
+def resource_rows():
+    ru = _built_library()
+    return ru.table(LIB)
 
 
 _REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -60,21 +58,9 @@ def _vregs(operand):
 
 def _parse(text):
     """-> list of functions, each a list of (mnemonic, [operands])"""
-    funcs, cur = [], None
-    for line in text.splitlines():
-        if re.match(r"^[0-9a-f]+ <.*>:$", line):
-            cur = []
-            funcs.append(cur)
-            continue
-        if cur is None or "\t" not in line:
-            continue
-        body = line.split("//")[0].strip()
-        if not body:
-            continue
-        parts = body.split(None, 1)
-        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
-        cur.append((parts[0], ops))
-    return funcs
+    from stac_mjx_amd.resource_usage import parse_disassembly
+
+    return list(parse_disassembly(text).values())
 
 
 def _wait_states(ins):
@@ -123,3 +109,114 @@ def test_no_dpp_read_after_write_hazard(tmp_path):
     n_dpp, bad = _hazards(_disassemble(tmp_path))
     assert n_dpp > 1000, f"the FK program's DPP code was expected in the library ({n_dpp} DPP instructions found)"
     assert not bad, f"{len(bad)} DPP hazards, e.g. {bad[:3]}"
+
+
+# ---- register spills and scratch: the fence round 3's stale-scratch defect asked for -------------------------
+# Two latency-kernel shapes of round 3 (150 spilled VGPRs on top of 235 SGPRs spilled into VGPR lanes) read spill slots that
+# the launch had not written: results depended on what the previous launch left in scratch.  No source-level cause was found, so
+# the class is fenced off instead: (1) no instantiation that the host can dispatch may spill more than a handful of registers
+# (the table: `python -m stac_mjx_amd.resource_usage`, committed per round as profiles/rNN/resource_usage.txt); (2) every
+# scratch load that remains must be preceded by a store to the same bytes on EVERY path from the kernel's entry (forward
+# dataflow over the control-flow graph rebuilt from the disassembly); (3) no run-time-indexed private memory and no calls.
+MAX_SCRATCH_BYTES = 32      # per lane; today's worst shipped shape: 24 B (three 128-VGPR variants of the 32- / 64-lane kernel)
+MAX_VGPR_SPILLS = 16        # today's worst: 15
+MAX_SGPR_SPILLS = 40        # into VGPR lanes (harmless without scratch, but each costs a v_readlane per use); worst: 34 (LM, 16 x 16)
+
+
+def test_no_shipped_instantiation_spills_beyond_the_gate(resource_rows):
+    solver = [r for r in resource_rows if r["kernel"].startswith(("q_phase_kernel", "q_phase_lm_kernel"))]
+    assert len(solver) >= 20, "the q_phase instantiations were expected in the library"
+    bad = [(r["kernel"], r["private_segment_fixed_size"], r["vgpr_spill_count"], r["sgpr_spill_count"]) for r in resource_rows
+           if r["private_segment_fixed_size"] > MAX_SCRATCH_BYTES or r["vgpr_spill_count"] > MAX_VGPR_SPILLS
+           or r["sgpr_spill_count"] > MAX_SGPR_SPILLS]
+    assert not bad, f"(kernel, scratch bytes, VGPR spills, SGPR spills) beyond the gate: {bad}"
+    # the kernels the headline bench and its 250-frame-clip leg run: nothing in scratch at all
+    for name in ("q_phase_kernel<16, 5, 3, 0>", "q_phase_kernel<16, 5, 2, 4>", "q_phase_kernel<32, 3, 2, 8>"):
+        (r,) = [r for r in resource_rows if r["kernel"] == name]
+        assert r["private_segment_fixed_size"] == 0 and r["sgpr_spill_count"] < 32, r
+
+
+def test_every_scratch_load_is_dominated_by_a_store(resource_rows):
+    bad = [(r["kernel"], r["scr_bad_list"][:3]) for r in resource_rows if r["scr_bad"]]
+    assert not bad, f"scratch bytes loaded before they are stored on some path: {bad}"
+    # the lanes of the VGPRs that carry spilled SGPRs (v_writelane / v_readlane) likewise: registers are not cleared between wavefronts
+    bad = [(r["kernel"], r["lane_bad_list"][:3]) for r in resource_rows if r["lane_bad"]]
+    assert not bad, f"SGPR spill lanes read before they are written on some path: {bad}"
+    dyn = [(r["kernel"], r["scr_dyn"], r["indirect"]) for r in resource_rows if r["scr_dyn"] or r["indirect"]]
+    assert not dyn, f"run-time-indexed private memory / indirect branches (not analysable): {dyn}"
+
+
+def _ins(text):
+    from stac_mjx_amd.resource_usage import parse_disassembly_addr
+
+    (f,) = parse_disassembly_addr(text).values()
+    return f
+
+
+def test_the_first_access_checker_sees_a_load_before_its_store():
+    from stac_mjx_amd.resource_usage import scratch_first_access
+
+    # slot 8 is stored only on the fall-through path of the branch at 0x1004, and loaded after the join
+    fake = """
+0000000000001000 <k>:
+\tv_mov_b32_e32 v1, 0                                          // 000000001000: 7E020280
+\ts_cbranch_scc1 1                                             // 000000001004: BF850001 <k+0xc>
+\tscratch_store_dword off, v1, off offset:8                    // 000000001008: DC000000
+\tscratch_store_dword off, v1, off offset:12                   // 00000000100C: DC000000
+\tscratch_load_dword v2, off, off offset:8                     // 000000001010: DC000000
+\tscratch_load_dword v3, off, off offset:12                    // 000000001014: DC000000
+\ts_endpgm                                                     // 000000001018: BF810000
+"""
+    fa = scratch_first_access(_ins(fake))
+    assert fa["loads"] == 2 and fa["stores"] == 2 and [b[2] for b in fa["bad"]] == [8]
+    # a loop whose body loads what only its latch stores: bad on the first trip
+    loop = """
+0000000000002000 <k>:
+\tscratch_store_dword off, v1, off offset:4                    // 000000002000: DC000000
+\tscratch_load_dwordx2 v[2:3], off, off offset:4               // 000000002004: DC000000
+\tscratch_store_dword off, v1, off offset:8                    // 000000002008: DC000000
+\ts_cbranch_vccnz 65532                                        // 00000000200C: BF87FFFC <k+0x4>
+\ts_endpgm                                                     // 000000002010: BF810000
+"""
+    fa = scratch_first_access(_ins(loop))
+    assert len(fa["bad"]) == 1 and fa["bad"][0][2:] == (4, 4)  # the upper four bytes of the 8-byte load
+    # stored on both arms of a diamond: fine; a VGPR-addressed access: reported as dynamic
+    ok = """
+0000000000003000 <k>:
+\ts_cbranch_scc0 2                                             // 000000003000: BF840002 <k+0xc>
+\tscratch_store_dword off, v1, off                             // 000000003004: DC000000
+\ts_branch 1                                                   // 000000003008: BF820001 <k+0x10>
+\tscratch_store_dword off, v4, off                             // 00000000300C: DC000000
+\tscratch_load_dword v2, off, off                              // 000000003010: DC000000
+\tscratch_load_dword v2, v9, off offset:16                     // 000000003014: DC000000
+\ts_endpgm                                                     // 000000003018: BF810000
+"""
+    fa = scratch_first_access(_ins(ok))
+    assert not fa["bad"] and fa["dynamic"] == 1 and fa["loads"] == 1
+    # SGPR spill lanes: lane 3 of v40 is read on a path that skips its v_writelane
+    lanes = """
+0000000000004000 <k>:
+\tv_writelane_b32 v40, s4, 2                                   // 000000004000: D28A0028
+\ts_cbranch_scc1 1                                             // 000000004008: BF850001 <k+0x10>
+\tv_writelane_b32 v40, s5, 3                                   // 00000000400C: D28A0028
+\tv_readlane_b32 s6, v40, 2                                    // 000000004010: D2890006
+\tv_readlane_b32 s7, v40, 3                                    // 000000004018: D2890007
+\ts_endpgm                                                     // 000000004020: BF810000
+"""
+    fa = scratch_first_access(_ins(lanes))
+    assert fa["lane_loads"] == 2 and fa["lane_stores"] == 2 and [b[2:] for b in fa["lane_bad"]] == [("v40", 3)]
+
+
+def test_every_solver_instantiation_is_launched_by_the_gpu_suite(resource_rows):
+    """profiles/rNN/gpu_suite_kernels.txt is the kernel list of a traced run of the -m gpu suite (rocprofv3 --kernel-trace,
+    profiles/tools/suite_coverage.sh).  Every q_phase / LM instantiation in the built library must be in the newest one with at
+    least two launches: an instantiation nobody launches twice is one whose spills nobody has checked against stale state."""
+    lists = sorted((ROOT / "profiles").glob("r*/gpu_suite_kernels.txt"))
+    assert lists, "no committed coverage list (profiles/rNN/gpu_suite_kernels.txt)"
+    calls = {}
+    for line in lists[-1].read_text().splitlines():
+        n, name = line.split(None, 1)
+        calls[name.strip()] = int(n)
+    want = [r["kernel"] for r in resource_rows if r["kernel"].startswith(("q_phase_kernel", "q_phase_lm_kernel"))]
+    missing = [k for k in want if calls.get(k, 0) < 2]
+    assert not missing, f"not launched (twice) by the GPU suite according to {lists[-1]}: {missing}"
