@@ -109,6 +109,122 @@ __device__ __forceinline__ float group_tree_sum(const float (&v)[NQR]) {
     return t[0];
 }
 
+// ---- launch arguments as the trip loop sees them ---------------------------------------------------------------------------
+// QArgs is 424 bytes of kernel argument.  Read once in the prologue, every field -- and every address or lane mask derived
+// from one -- stays live across the whole trip loop: the kernels ran with 100 to 310 scalars spilled into vector-register
+// lanes.  Inside the loop the arguments are therefore seen through two views with the members' own names:
+//   * the fields that every trip uses are scalars PINNED before the loop (made opaque, so that the compiler neither
+//     re-derives nor re-loads them: they simply occupy ~40 of the 102 scalar registers);
+//   * everything else is a reference into the kernarg segment through a pointer that is laundered inside the loop: a cold
+//     field is fetched by a scalar load where it is used (the constant cache holds the segment) and is dead afterwards.
+template <class T>
+using KRef = const __attribute__((address_space(4))) T &;
+template <class T>
+__device__ __forceinline__ T pin_scalar(T v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+template <class T>
+__device__ __forceinline__ T pin_vector(T v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// How a field is kept across the trip loop: S = pinned in a scalar register; V = pinned in a vector register where the kernel
+// has vector registers to spare (VPIN: the latency kernels; an offset that is only ever added to a lane's address costs
+// nothing there), else re-read; N = re-read from the kernarg segment where it is used.
+#ifndef STAC_PIN_ADDR
+#define STAC_PIN_ADDR V
+#endif
+#ifndef STAC_PIN_CTL
+#define STAC_PIN_CTL N
+#endif
+enum PinClass { PIN_N = 0, PIN_S = 1, PIN_V = 2 };
+#define STAC_PINCLASS_(c) PIN_##c
+#define STAC_PINCLASS(c) STAC_PINCLASS_(c)
+// (field, class): loop bounds, flags and sizes that feed scalar compares and branches; then LDS offsets
+#ifndef STAC_PIN_CTL2
+#define STAC_PIN_CTL2 STAC_PIN_CTL
+#endif
+#define STAC_HOT_HEADER_FIELDS(X)                                                                                              \
+    X(nq, STAC_PIN_CTL2) X(K, STAC_PIN_CTL2) X(nqpad, N) X(naj, STAC_PIN_CTL) X(nrange, STAC_PIN_CTL) X(max_width, STAC_PIN_CTL) \
+    X(fk_hdr_words, STAC_PIN_CTL2) X(n_mlev_hdr, STAC_PIN_CTL2) X(n_mlev, STAC_PIN_CTL2) X(fk_rec_words, STAC_PIN_CTL2)         \
+    X(fk_uniform, STAC_PIN_CTL2)                                                                                               \
+    X(off_joint, STAC_PIN_ADDR) X(off_site, STAC_PIN_ADDR) X(off_lb, STAC_PIN_ADDR) X(off_ub, STAC_PIN_ADDR)                    \
+    X(off_range, STAC_PIN_ADDR) X(off_fkstep, STAC_PIN_ADDR) X(off_fkroot, STAC_PIN_ADDR) X(c_bx, STAC_PIN_ADDR)                \
+    X(c_ja, STAC_PIN_ADDR) X(c_jn, STAC_PIN_ADDR) X(c_sw, STAC_PIN_ADDR) X(c_sink, STAC_PIN_ADDR) X(c_rw, STAC_PIN_ADDR)        \
+    X(c_qe, STAC_PIN_ADDR) X(c_qsv, STAC_PIN_ADDR) X(chain_stride, STAC_PIN_ADDR)
+#define STAC_HOT_ARGS_FIELDS(X)                                                                                                \
+    X(single, STAC_PIN_CTL) X(P, STAC_PIN_CTL2) X(flags, STAC_PIN_CTL) X(free0p, STAC_PIN_CTL) X(root_fast, STAC_PIN_CTL)       \
+    X(n_mlev_root, STAC_PIN_CTL2) X(n_run_root, STAC_PIN_CTL2) X(n_root_joints, STAC_PIN_CTL2) X(maxls, STAC_PIN_CTL)           \
+    X(maxiter, STAC_PIN_CTL2) X(queue_slots, N) X(resume, N) X(root_trunk_lo, N) X(root_trunk_hi, N) X(tol, STAC_PIN_CTL2)
+template <bool VPIN, PinClass C, class T>
+__device__ __forceinline__ T pin_as(T v) {
+    if constexpr (C == PIN_S) return pin_scalar(v);
+    else if constexpr (C == PIN_V && VPIN) return pin_vector(v);
+    else return v;
+}
+template <bool VPIN, PinClass C>
+constexpr bool is_pinned() { return C == PIN_S || (C == PIN_V && VPIN); }
+struct HotHeader {  // PlanHeader fields of every trip (values)
+    int32_t nq, K, nqpad, naj, nrange, max_width, off_joint, off_site, off_lb, off_ub, off_range, off_fkstep, off_fkroot, fk_hdr_words,
+        n_mlev_hdr, n_mlev, fk_rec_words, fk_uniform, c_bx, c_ja, c_jn, c_sw, c_sink, c_rw, c_qe, c_qsv, chain_stride;
+};
+template <bool VPIN, class KH>
+__device__ __forceinline__ HotHeader pin_header(const KH &h) {  // before the loop: the pinned ones
+    HotHeader o = {};
+#define STAC_PIN(f, c) if constexpr (is_pinned<VPIN, STAC_PINCLASS(c)>()) o.f = pin_as<VPIN, STAC_PINCLASS(c)>(h.f);
+    STAC_HOT_HEADER_FIELDS(STAC_PIN)
+#undef STAC_PIN
+    return o;
+}
+struct TripHeader : HotHeader {  // + the other PlanHeader fields (references into the kernarg segment)
+    KRef<int32_t> nbody, njnt, nab, nlev, nquat, has_ball, off_lev_adr, off_body, off_qpos0, off_quat_adr, off_active, total_words,
+        plan_skip, core_words, c_gg, c_kp, c_r2, stride_regs, stride_lds, stride_forced, nst, nqj, kpow2;
+};
+template <bool VPIN, class KH>
+__device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH &k) {  // inside the loop: pinned values + fresh reads
+    HotHeader t = hot;
+#define STAC_PIN(f, c) if constexpr (!is_pinned<VPIN, STAC_PINCLASS(c)>()) t.f = k.f;
+    STAC_HOT_HEADER_FIELDS(STAC_PIN)
+#undef STAC_PIN
+    return TripHeader{t, k.nbody, k.njnt, k.nab, k.nlev, k.nquat, k.has_ball, k.off_lev_adr, k.off_body, k.off_qpos0, k.off_quat_adr,
+                      k.off_active, k.total_words, k.plan_skip, k.core_words, k.c_gg, k.c_kp, k.c_r2, k.stride_regs, k.stride_lds,
+                      k.stride_forced, k.nst, k.nqj, k.kpow2};
+}
+static_assert(sizeof(PlanHeader) == (27 + 23) * 4, "TripHeader must list every PlanHeader field");
+struct HotArgs {  // QArgs fields of every trip (values)
+    int32_t single, P, flags, free0p, root_fast, n_mlev_root, n_run_root, n_root_joints, maxls, maxiter, queue_slots, resume;
+    uint32_t root_trunk_lo, root_trunk_hi;
+    float tol;
+};
+template <bool VPIN, class KA>
+__device__ __forceinline__ HotArgs pin_args(const KA &a) {
+    HotArgs o = {};
+#define STAC_PIN(f, c) if constexpr (is_pinned<VPIN, STAC_PINCLASS(c)>()) o.f = pin_as<VPIN, STAC_PINCLASS(c)>(a.f);
+    STAC_HOT_ARGS_FIELDS(STAC_PIN)
+#undef STAC_PIN
+    return o;
+}
+struct TripArgs : HotArgs {
+    KRef<const float *> kp, q_init;
+    KRef<const uint8_t *> kpw, kpw3;
+    KRef<const int32_t *> perm;
+    KRef<int32_t> C, F, root_kp_idx, do_root_opt;
+    KRef<int32_t *> ctl;
+    KRef<float *> hand, qpos_out, err_out;
+    KRef<uint32_t *> counters_out;
+    KRef<float *> q_carry_out;
+};
+template <bool VPIN, class KA>
+__device__ __forceinline__ TripArgs trip_args(const HotArgs &hot, const KA &k) {
+    HotArgs t = hot;
+#define STAC_PIN(f, c) if constexpr (!is_pinned<VPIN, STAC_PINCLASS(c)>()) t.f = k.f;
+    STAC_HOT_ARGS_FIELDS(STAC_PIN)
+#undef STAC_PIN
+    return TripArgs{t, k.kp, k.q_init, k.kpw, k.kpw3, k.perm, k.C, k.F, k.root_kp_idx, k.do_root_opt, k.ctl, k.hand, k.qpos_out, k.err_out,
+                    k.counters_out, k.q_carry_out};
+}
+
 enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4, ST_WAIT = 5, ST_NEXT = 6 };
 
 // In-kernel phase stamps: diagnostic build only (-DSTAC_PROFILE -> libstac_hip_prof.so); the stamps

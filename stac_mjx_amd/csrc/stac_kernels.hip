@@ -197,7 +197,8 @@ void q_phase_kernel(const QArgs a_in) {
     float x[NQR], y[NQR], g[NQR], q0[NQR];
     // the lane's bounds: from the plan in LDS where registers are short (throughput kernels), in registers in latency mode
     // (a trip reads them four times per coordinate)
-    constexpr bool BREG = SPEC != 0;
+    // (latency kernels; throughput kernels where the register cap leaves room: +3 % on the 10 000-frame bench at 164 of 168 VGPRs)
+    constexpr bool BREG = SPEC != 0 || (WPE == 2 && NQR <= 8) || (WPE == 3 && NQR <= 5);
     float lbr[BREG ? NQR : 1], ubr[BREG ? NQR : 1];
     if constexpr (BREG) {
 #pragma unroll
@@ -314,14 +315,16 @@ void q_phase_kernel(const QArgs a_in) {
     // site pass covers them all (sites1)
     int trunk_r = -1;
     bool sites1 = false;
-    if (!SPEC && a.root_fast > 0 && site_regs && a.kpw) {
+    // (the trunk weights of the lane's sites as bits: the root passes' site terms would fetch them from global memory in every trip)
+    uint32_t kpw_bits = 0;
+    if (!a.single && site_regs && a.kpw) {
         int cnt = 0;
 #pragma unroll
         for (int r = 0; r < NSR; ++r) {
             const int k = r * G + lg;
-            if (k < K && a.kpw[k]) { trunk_r = r; ++cnt; }
+            if (k < K && a.kpw[k]) { trunk_r = r; ++cnt; kpw_bits |= 1u << r; }
         }
-        sites1 = !__any(cnt > 1);
+        sites1 = !SPEC && a.root_fast > 0 && !__any(cnt > 1);
     }
     PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
@@ -338,14 +341,27 @@ void q_phase_kernel(const QArgs a_in) {
     typedef const __attribute__((address_space(4))) QArgs KQArgs;
     KQArgs *const ak_base = (KQArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr bool kReloadPerTrip = SPEC == 0;
+#ifndef STAC_VPIN
+#define STAC_VPIN (SPEC != 0 && G >= 16)
+#endif
+#ifndef STAC_NO_PIN
+    constexpr bool kVPin = STAC_VPIN;
+    const HotHeader hot_h = pin_header<kVPin>(a.h);
+    const HotArgs hot_a = pin_args<kVPin>(a);
+#endif
     const int cb_words = (int)(CB - lds);
     while (__any(st != ST_DONE)) {
         PROF_TICK(0);  // loop control
         PROF_TRIP;
         KQArgs *ak_t = ak_base;
         if constexpr (kReloadPerTrip) asm volatile("" : "+s"(ak_t));
+#ifndef STAC_NO_PIN
+        const TripArgs a = trip_args<kVPin>(hot_a, *ak_t);
+        const TripHeader H = trip_header<kVPin>(hot_h, ak_t->h);
+#else
         KQArgs &a = *ak_t;
         const auto &H = a.h;
+#endif
         // ... and neither does anything derived from it: the names below shadow the prologue's
         const int nq = H.nq, K = H.K, nqpad = H.nqpad;
         const int plan_words = (H.total_words - H.plan_skip + 3) & ~3;
@@ -550,7 +566,7 @@ void q_phase_kernel(const QArgs a_in) {
         const int Kpad = (K + 3) & ~3;
         // one site: world position, weighted residual against the keypoint (kx, ky, kz), loss term; the wrench
         // (f, (x - c) x f) goes to its place in DFS-site order
-        auto site_term = [&](const int k, const float kx, const float ky, const float kz) -> float {
+        auto site_term = [&](const int k, const float kx, const float ky, const float kz, const bool tw) -> float {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
             const float *bp = bx + (ss & 0xFFFF) * kXf;
@@ -559,7 +575,7 @@ void q_phase_kernel(const QArgs a_in) {
             if (a.single) {
                 w0 = a.kpw3[3 * k] ? 1.f : 0.f; w1 = a.kpw3[3 * k + 1] ? 1.f : 0.f; w2 = a.kpw3[3 * k + 2] ? 1.f : 0.f;
             } else {
-                w0 = w1 = w2 = (trunk_w ? (a.kpw[k] ? 1.f : 0.f) : 1.f);
+                w0 = w1 = w2 = (trunk_w ? (tw ? 1.f : 0.f) : 1.f);
             }
             // a site without weight: exact zeros, written without looking at its body (which a pruned FK has skipped)
             const bool wz = (w0 == 0.0f) && (w1 == 0.0f) && (w2 == 0.0f);
@@ -587,7 +603,7 @@ void q_phase_kernel(const QArgs a_in) {
                     const float kx = trunk_r == 0 ? kpr[0][0] : (trunk_r == 1 ? kpr[1][0] : kpr[NSR - 1][0]);
                     const float ky = trunk_r == 0 ? kpr[0][1] : (trunk_r == 1 ? kpr[1][1] : kpr[NSR - 1][1]);
                     const float kz = trunk_r == 0 ? kpr[0][2] : (trunk_r == 1 ? kpr[1][2] : kpr[NSR - 1][2]);
-                    v = site_term(trunk_r * G + lg, kx, ky, kz);
+                    v = site_term(trunk_r * G + lg, kx, ky, kz, true);
                 }
 #pragma unroll
                 for (int r = 0; r < NSR; ++r) term[r] = r == trunk_r ? v : 0.0f;
@@ -595,7 +611,7 @@ void q_phase_kernel(const QArgs a_in) {
 #pragma unroll
             for (int r = 0; r < NSR; ++r) {
                 const int k = r * G + lg;
-                term[r] = k < K ? site_term(k, kpr[r][0], kpr[r][1], kpr[r][2]) : 0.0f;
+                term[r] = k < K ? site_term(k, kpr[r][0], kpr[r][1], kpr[r][2], ((kpw_bits >> r) & 1u) != 0) : 0.0f;
             }
             }
             loss = group_tree_sum<G, NSR>(term);
@@ -603,7 +619,7 @@ void q_phase_kernel(const QArgs a_in) {
             PROF_TICK(3);  // sites + loss
         } else {
         for (int k = K + lg; k < (K > 64 ? H.kpow2 : Kpad); k += G) r2[k] = 0.0f;  // zero padding of the loss tree
-        for (int k = lg; k < K; k += G) r2[k] = site_term(k, kpl[3 * k], kpl[3 * k + 1], kpl[3 * k + 2]);
+        for (int k = lg; k < K; k += G) r2[k] = site_term(k, kpl[3 * k], kpl[3 * k + 1], kpl[3 * k + 2], trunk_w && a.kpw[k] != 0);
         wave_sync();
         PROF_TICK(3);  // sites
         // pairwise tree over the sites (oracle: tree_sum), every lane redundantly from broadcast LDS reads:
@@ -1085,8 +1101,13 @@ void q_phase_kernel(const QArgs a_in) {
             // (cold: once per solve.  What it needs of the launch is read here, whatever the trip keeps in registers)
             KQArgs *ak_c = ak_base;
             asm volatile("" : "+s"(ak_c));
+#ifndef STAC_NO_PIN
+            const TripArgs a = trip_args<kVPin>(hot_a, *ak_c);
+            const TripHeader H = trip_header<kVPin>(hot_h, ak_c->h);
+#else
             KQArgs &a = *ak_c;
             const auto &H = a.h;
+#endif
             const int nq = H.nq, K = H.K;
             const int *const quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
             const TripCtx cx{lg, nq, K, CB + H.c_kp, P + H.off_lb, P + H.off_ub, P + H.off_qpos0};
@@ -1427,7 +1448,7 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 // (lanes per chain G, solver registers per lane NQR: nq <= G * NQR, register cap WPE).  Every shape here passes the resource
 // gate of tests/test_isa_hazards.py (scratch <= 64 B per lane, <= 40 scalars spilled into vector lanes; table:
 // profiles/r04/resource_usage.txt).  What does not is not built: the 128-VGPR variants of the 8- and 16-lane kernels (74 to 750
-// spilled vector registers), 32 solver registers per lane at 4 or 8 lanes and the 4-lane kernels altogether (160 B to 1.3 KB of
+// spilled vector registers) and of the 32- / 64-lane kernels with four or more solver registers per lane (17 to 80), 32 solver registers per lane at 4 or 8 lanes and the 4-lane kernels altogether (160 B to 1.3 KB of
 // scratch; never chosen automatically, slower than 16 lanes at every batch size) -- a request for them runs on the next wider
 // group, results are the same bit for bit.  Latency kernels stop at 10 solver registers per lane at 8 lanes and 8 at 16 or 32
 // (round 3: the wider ones, 300+ B of scratch, read spill slots before writing them); wider models take more lanes per role.
@@ -1438,8 +1459,8 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
     X(16, 5, 2) X(16, 5, 3) X(16, 8, 2) X(16, 8, 3) X(16, 16, 2)                 \
-    X(32, 3, 2) X(32, 3, 4) X(32, 4, 2) X(32, 4, 4) X(32, 8, 2)                  \
-    X(64, 2, 2) X(64, 2, 4) X(64, 4, 2) X(64, 4, 4)
+    X(32, 3, 2) X(32, 3, 4) X(32, 4, 2) X(32, 8, 2)                              \
+    X(64, 2, 2) X(64, 2, 4) X(64, 4, 2)
 // (G lanes per role, NQR, roles per chain)
 #define STAC_Q_SPEC_SHAPES(X)                                                   \
     X(8, 10, 4) X(8, 10, 8) X(16, 5, 4) X(16, 8, 4) X(32, 3, 8) X(32, 8, 8) X(64, 2, 8) X(64, 4, 8)
