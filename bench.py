@@ -137,6 +137,105 @@ def run_fit_mode(args, rank, local_rank, world, dist):
         print(json.dumps(line))
 
 
+def run_run_mode(args, rank, local_rank, world, dist):
+    """--mode run: the PRODUCT path end to end -- `Stac.ik_only` (stac_mjx/stac.py:356-454) on synthetic frames with every
+    output (qpos, xpos, xquat, marker_sites; 2 728 B per rodent frame), then `io.save_data_to_h5`
+    (stac_mjx/io.py:194-237).  Reports where the wall time goes: batching + upload, the q_phase and FK kernels, download +
+    packing, the file write; and the FK output pass on its own (HIP events) against the HBM roofline of its 2 448 + 296
+    algorithmic bytes per pose.  `value` = frames/s of ik_only itself (file write excluded and reported beside it)."""
+    import tempfile
+
+    from stac_mjx_amd import io as sio
+    from stac_mjx_amd.config import validate_config
+    from stac_mjx_amd.stac import Stac
+    from stac_mjx_amd.synth import synth_keypoints, synth_offsets
+
+    fs, mcfg = load_setup("rodent")
+    F = args.frames_per_clip if args.frames_per_clip > 1 else 250
+    C = max(args.frames // F, 1)
+    cfg = validate_config({"model": dict(mcfg), "stac": dict(
+        fit_offsets_path="fit.h5", ik_only_path="ik.h5", data_path="synthetic", continuous=False, n_fit_frames=F,
+        skip_fit_offsets=True, skip_ik_only=False, infer_qvels=False, n_frames_per_clip=F, gather="none",
+        mujoco=dict(solver="newton", iterations=1, ls_iterations=4))})
+    stac = Stac(None, cfg, fs.kp_names, setup=fs, device=f"cuda:{local_rank}", verbose=False)
+    eng = stac.engine
+    offsets = synth_offsets(fs)
+    eng.set_site_pos(offsets)
+    fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
+    kp_host, _ = synth_keypoints(fs, fk, C, F, seed=1000 * rank + 11, noise_seed=1000 * rank + 12)
+    kp_flat = kp_host.reshape(C * F, -1)
+    nq, nb, K = fs.tables.nq, fs.tables.nbody, fs.tables.nsite
+    for _ in range(args.warmup):
+        stac.ik_only(kp_flat, offsets)
+    phases, walls, writes = {}, [], []
+    data = None
+    for _ in range(args.steps):
+        stac.timings = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        data = stac.ik_only(kp_flat, offsets)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        for k, v in stac.timings.items():
+            phases[k] = phases.get(k, 0.0) + v / args.steps
+        stac.timings = None
+    with tempfile.TemporaryDirectory() as td:
+        t0 = time.perf_counter()
+        out = sio.save_data_to_h5(cfg, data.kp_names, data.names_qpos, data.names_xpos, data.kp_data, data.marker_sites, data.offsets,
+                                  data.qpos, data.xpos, data.xquat, np.array([]), Path(td) / "ik_only.h5")
+        write_s = time.perf_counter() - t0
+        written = (out.name, out.stat().st_size)
+    # the kernels on their own (HIP events on the launch stream): q_phase without outputs, then the FK output pass over its result
+    kp = torch.as_tensor(kp_host).to(eng.device)
+    kw = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=max(fs.root_kp_idx, 0), root_dims=fs.root_dims,
+              do_root_opt=fs.do_root_opt)
+    res = eng.q_phase(kp, want_bodies=False, want_markers=False, **kw)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    res = eng.q_phase(kp, want_bodies=False, want_markers=False, out=res, **kw)
+    e[1].record()
+    qflat = res["qpos"].reshape(-1, nq)
+    fko = eng.fk(qflat)
+    fk_ms = []
+    for _ in range(5):
+        e[2].record()
+        fko = eng.fk(qflat)
+        e[3].record()
+        torch.cuda.synchronize()
+        fk_ms.append(e[2].elapsed_time(e[3]))
+    q_ms, fk_ms = e[0].elapsed_time(e[1]), float(np.median(fk_ms))
+    fk_bytes = C * F * (4 * nq * 2 + 12 * nb + 16 * nb + 12 * K)  # qpos in, normalised qpos + xpos + xquat + marker sites out
+    wall = float(np.mean(walls))
+    frames = C * F
+    gpu_side = phases.get("q_phase_and_fk_kernels_s", 0.0)
+    line = {
+        "metric": "frames/sec Stac.ik_only end to end (rodent, 23 kp, all outputs)", "value": world * frames / wall, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"Stac.ik_only: {frames} synthetic rodent frames per GPU as {C} clips of {F} (reference default chaining), "
+                        f"qpos + xpos + xquat + marker_sites = {4 * nq + 28 * nb + 12 * K + 4} B per frame out, PG parity mode",
+            "frames_per_gpu": frames, "n_frames_per_clip": F,
+            "phases_s": {**{k: round(v, 4) for k, v in phases.items()}, "ik_only_wall_s": round(wall, 4),
+                         "save_data_to_h5_s": round(write_s, 3)},
+            "file_written": {"name": written[0], "bytes": written[1],
+                             "note": "gzip datasets like the reference (io.py:224-236); .npz stand-in where this interpreter has no h5py"},
+            "kernels_ms": {"q_phase_no_outputs": round(q_ms, 3), "fk_output_pass": round(fk_ms, 4)},
+            "q_phase_share_of_gpu_side_time": q_ms * 1e-3 / gpu_side if gpu_side else None,
+            "fk_output_pass": {"algorithmic_bytes": fk_bytes, "achieved_GBps": fk_bytes / (fk_ms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": fk_bytes / (fk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "d2h_bytes": frames * (4 * nq + 28 * nb + 12 * K + 4),
+        },
+        "roofline": {"bound": "hbm", "achieved": frames * (12 * K + 4 * nq + 28 * nb + 12 * K + 4) / gpu_side / 1e9 if gpu_side else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (frames * (12 * K + 4 * nq + 28 * nb + 12 * K + 4) / gpu_side / 1e9 / HBM_PEAK_GBS) if gpu_side else None,
+                     "traffic": None, "kernel": "stac::q_phase_kernel + stac::fk_kernel (ik_only, all outputs)",
+                     "algorithmic_bytes_per_frame": 12 * K + 4 * nq + 28 * nb + 12 * K + 4},
+    }
+    if rank == 0:
+        print(json.dumps(line))
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (never re-exec a process that
     may have touched the GPU; counting devices does not initialise HIP) and return their exit code.  Rank 0 of the
@@ -177,9 +276,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the clips250 and LM legs (profiling runs)")
-    ap.add_argument("--mode", default="ik", choices=["ik", "fit"],
+    ap.add_argument("--mode", default="ik", choices=["ik", "fit", "run"],
                     help="ik = q_phase only (the BASELINE metric); fit = offset/pose alternation on clips sharded over the "
-                         "ranks with the offset-phase all-reduce over RCCL (stac.fit_frames_per_clip), reported as frame-solves/s")
+                         "ranks with the offset-phase all-reduce over RCCL (stac.fit_frames_per_clip), reported as frame-solves/s; "
+                         "run = Stac.ik_only end to end with every output + the result file, phase by phase")
     ap.add_argument("--solver", default="pg", choices=["pg", "lm"],
                     help="pg = the reference's projected gradient (parity mode, the BASELINE metric); lm = optional fast solver")
     ap.add_argument("--lm-maxiter", type=int, default=20, help="--solver lm: accepted LM steps per solve (engine default 20)")
@@ -203,8 +303,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    if args.mode == "fit":
-        run_fit_mode(args, rank, local_rank, world, dist)
+    if args.mode in ("fit", "run"):
+        (run_fit_mode if args.mode == "fit" else run_run_mode)(args, rank, local_rank, world, dist)
         if dist:
             dist.destroy_process_group()
         return

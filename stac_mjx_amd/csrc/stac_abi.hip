@@ -757,13 +757,7 @@ static int fk_impl(const stac_model *mc, const float *qpos, int32_t N, float *qn
     if (!m || !qpos || N < 0) return fail(STAC_ERR_INVALID, "stac_fk: bad argument");
     if (N == 0) return STAC_OK;
     DeviceGuard dg(m);
-    const size_t nb = m->h.nbody;
-    if (!xpos || !xquat) {
-        const int rc = ensure_scratch(m, (size_t)N * nb * 7);
-        if (rc != STAC_OK) return rc;
-        if (!xpos) xpos = m->d_scratch;
-        if (!xquat) xquat = m->d_scratch + (size_t)N * nb * 3;
-    }
+    // (outputs the caller does not want are not written: the body transforms live in the kernel's LDS rows)
     HIP_TRY(launch_fk(m->full(), qpos, N, qn, xpos, xquat, site_xpos, normalize, (hipStream_t)stream));
     return STAC_OK;
 }

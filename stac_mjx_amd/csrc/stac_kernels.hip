@@ -1227,62 +1227,133 @@ void q_phase_kernel(const QArgs a_in) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// stand-alone forward kinematics: one thread per pose, whole body tree (utils.kinematics)
+// stand-alone forward kinematics: one lane per pose, whole body tree (utils.kinematics)
 // ------------------------------------------------------------------------------------------------
+// The outputs are the bulk of what Stac.ik_only produces (rodent: 2 448 of 2 728 B per frame), so they leave the chip as
+// full cache lines: a workgroup keeps the body transforms of its pb poses in LDS -- one row per pose, odd row strides, so
+// that the lanes' private rows sit in different banks and a child's read of its parent never leaves the CU (it used to be a
+// global round trip through the output array) -- and all 64 lanes then copy the rows out, consecutive lanes to consecutive
+// words of the pose-major arrays.  The marker sites are computed in that copy phase, one (pose, site) per lane.  Same
+// operations per pose as before: bit-identical to the oracle.
 // normalize = 0: quaternions in qpos are used as they are (the q_phase kernel has already applied
 // kinematics' write-back normalisation; MJX's xquat IS that stored quaternion).
+// The model tables (5 KB for the rodent) are staged in LDS as well: read from global memory body by body they put a
+// 1 us round trip on every step of a lane's serial walk down the tree.
+struct FkLds { int parent, jadr, jnum, bpos, bquat, jtype, jqadr, jpos, jaxis, q0, rows_p, rows_q, rows_c, total; };
+__host__ __device__ inline FkLds fk_lds_layout(int nbody, int njnt, int nq, int pb) {
+    FkLds L;
+    int o = 0;
+    L.parent = o; o += nbody;
+    L.jadr = o; o += nbody;
+    L.jnum = o; o += nbody;
+    L.bpos = o; o += 3 * nbody;
+    L.bquat = o; o += 4 * nbody;
+    L.jtype = o; o += njnt;
+    L.jqadr = o; o += njnt;
+    L.jpos = o; o += 3 * njnt;
+    L.jaxis = o; o += 3 * njnt;
+    L.q0 = o; o += nq;
+    L.rows_p = o; o += pb * ((3 * nbody) | 1);
+    L.rows_q = o; o += pb * ((4 * nbody) | 1);
+    L.rows_c = o; o += pb * (nq | 1);  // the poses' coordinates (normalised in place)
+    L.total = o;
+    return L;
+}
+// pb = poses per workgroup of 64 lanes (<= 64; the host sizes it so that several workgroups fit a CU's LDS)
 __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, int N, float *qpos_norm_out,
-                                                 float *xpos, float *xquat, float *site_xpos, int normalize) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float *q = qpos + (size_t)n * M.nq;
-    float *xp = xpos + (size_t)n * M.nbody * 3;
-    float *xq = xquat + (size_t)n * M.nbody * 4;
-    float *qn = qpos_norm_out ? qpos_norm_out + (size_t)n * M.nq : nullptr;
-    if (qn) for (int i = 0; i < M.nq; ++i) qn[i] = q[i];
-    xp[0] = xp[1] = xp[2] = 0.f;
-    xq[0] = 1.f; xq[1] = xq[2] = xq[3] = 0.f;
-    for (int b = 1; b < M.nbody; ++b) {
-        const int p = M.body_parentid[b];
-        const Q4 pquat = ld4(xq + 4 * p);
-        V3 pos = add3(ld3(xp + 3 * p), rotate(ld3(M.body_pos + 3 * b), pquat));
-        Q4 quat = qmul(pquat, ld4(M.body_quat + 4 * b));
-        const int j0 = M.body_jntadr[b], j1 = j0 + M.body_jntnum[b];
-        for (int j = j0; j < j1; ++j) {
-            const int ty = M.jnt_type[j], ad = M.jnt_qposadr[j];
-            const V3 jp = ld3(M.jnt_pos + 3 * j), jax = ld3(M.jnt_axis + 3 * j);
-            if (ty == JFREE) {
-                pos = ld3(q + ad);
-                float nn;
-                quat = normalize ? normalize4(ld4(q + ad + 3), &nn) : ld4(q + ad + 3);
-                if (qn) st4(qn + ad + 3, quat);
-            } else if (ty == JHINGE) {
-                const V3 anchor = add3(rotate(jp, quat), pos);
-                float sn, cs;
-                sincos_((q[ad] - M.qpos0[ad]) * 0.5f, &sn, &cs);
-                quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
-                pos = sub3(anchor, rotate(jp, quat));
-            } else if (ty == JSLIDE) {
-                const V3 axis = rotate(jax, quat);
-                const float d = q[ad] - M.qpos0[ad];
-                pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
-            } else {
-                const V3 anchor = add3(rotate(jp, quat), pos);
-                float nn;
-                const Q4 qloc = normalize ? normalize4(ld4(q + ad), &nn) : ld4(q + ad);
-                if (qn) st4(qn + ad, qloc);
-                quat = qmul(quat, qloc);
-                pos = sub3(anchor, rotate(jp, quat));
-            }
+                                                 float *xpos, float *xquat, float *site_xpos, int normalize, int pb) {
+    extern __shared__ float lds[];
+    const int t = threadIdx.x;
+    const int n0 = blockIdx.x * pb, nb = min(pb, N - n0);
+    const int WP = 3 * M.nbody, WQ = 4 * M.nbody, SP = WP | 1, SQ = WQ | 1;
+    const FkLds L = fk_lds_layout(M.nbody, M.njnt, M.nq, pb);
+    int *li = reinterpret_cast<int *>(lds);
+    for (int i = t; i < M.nbody; i += 64) { li[L.parent + i] = M.body_parentid[i]; li[L.jadr + i] = M.body_jntadr[i]; li[L.jnum + i] = M.body_jntnum[i]; }
+    for (int i = t; i < 3 * M.nbody; i += 64) lds[L.bpos + i] = M.body_pos[i];
+    for (int i = t; i < 4 * M.nbody; i += 64) lds[L.bquat + i] = M.body_quat[i];
+    for (int i = t; i < M.njnt; i += 64) { li[L.jtype + i] = M.jnt_type[i]; li[L.jqadr + i] = M.jnt_qposadr[i]; }
+    for (int i = t; i < 3 * M.njnt; i += 64) { lds[L.jpos + i] = M.jnt_pos[i]; lds[L.jaxis + i] = M.jnt_axis[i]; }
+    for (int i = t; i < M.nq; i += 64) lds[L.q0 + i] = M.qpos0[i];
+    float *rows_p = lds + L.rows_p, *rows_q = lds + L.rows_q, *rows_c = lds + L.rows_c;
+    const int SC = M.nq | 1;
+    {   // the block's coordinates: consecutive lanes read consecutive words of the pose-major input
+        const float *in = qpos + (size_t)n0 * M.nq;
+        int row = t / M.nq, col = t % M.nq;
+        for (int w = t; w < nb * M.nq; w += 64) {
+            rows_c[row * SC + col] = in[w];
+            col += 64;
+            while (col >= M.nq) { col -= M.nq; ++row; }
         }
-        st3(xp + 3 * b, pos);
-        st4(xq + 4 * b, quat);
     }
+    __syncthreads();
+    if (t < nb) {
+        float *q = rows_c + t * SC;  // (free / ball quaternions are normalised in place: what kinematics writes back)
+        float *xp = rows_p + t * SP, *xq = rows_q + t * SQ;
+        float *const qn = q;
+        xp[0] = xp[1] = xp[2] = 0.f;
+        xq[0] = 1.f; xq[1] = xq[2] = xq[3] = 0.f;
+        for (int b = 1; b < M.nbody; ++b) {
+            const int p = li[L.parent + b];
+            const Q4 pquat = ld4(xq + 4 * p);
+            V3 pos = add3(ld3(xp + 3 * p), rotate(ld3(lds + L.bpos + 3 * b), pquat));
+            Q4 quat = qmul(pquat, ld4(lds + L.bquat + 4 * b));
+            const int j0 = li[L.jadr + b], j1 = j0 + li[L.jnum + b];
+            for (int j = j0; j < j1; ++j) {
+                const int ty = li[L.jtype + j], ad = li[L.jqadr + j];
+                const V3 jp = ld3(lds + L.jpos + 3 * j), jax = ld3(lds + L.jaxis + 3 * j);
+                if (ty == JFREE) {
+                    pos = ld3(q + ad);
+                    float nn;
+                    quat = normalize ? normalize4(ld4(q + ad + 3), &nn) : ld4(q + ad + 3);
+                    st4(qn + ad + 3, quat);
+                } else if (ty == JHINGE) {
+                    const V3 anchor = add3(rotate(jp, quat), pos);
+                    float sn, cs;
+                    sincos_((q[ad] - lds[L.q0 + ad]) * 0.5f, &sn, &cs);
+                    quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
+                    pos = sub3(anchor, rotate(jp, quat));
+                } else if (ty == JSLIDE) {
+                    const V3 axis = rotate(jax, quat);
+                    const float d = q[ad] - lds[L.q0 + ad];
+                    pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
+                } else {
+                    const V3 anchor = add3(rotate(jp, quat), pos);
+                    float nn;
+                    const Q4 qloc = normalize ? normalize4(ld4(q + ad), &nn) : ld4(q + ad);
+                    st4(qn + ad, qloc);
+                    quat = qmul(quat, qloc);
+                    pos = sub3(anchor, rotate(jp, quat));
+                }
+            }
+            st3(xp + 3 * b, pos);
+            st4(xq + 4 * b, quat);
+        }
+    }
+    __syncthreads();
+    // copy phase: word w of the block's pose-major output <- row (w / W), column (w % W); the lanes walk (row, column) with
+    // additions only
+    auto copy_rows = [&](float *dst, const float *rows, const int W, const int S) {
+        if (!dst) return;
+        float *out = dst + (size_t)n0 * W;
+        int row = t / W, col = t % W;
+        for (int w = t; w < nb * W; w += 64) {
+            out[w] = rows[row * S + col];
+            col += 64;
+            while (col >= W) { col -= W; ++row; }
+        }
+    };
+    copy_rows(xpos, rows_p, WP, SP);
+    copy_rows(xquat, rows_q, WQ, SQ);
+    copy_rows(qpos_norm_out, rows_c, M.nq, SC);
     if (site_xpos) {
-        for (int k = 0; k < M.K; ++k) {
+        const int K = M.K;
+        int row = t / K, k = t % K;
+        for (int e = t; e < nb * K; e += 64) {
             const int b = M.site_bodyid[k];
-            st3(site_xpos + ((size_t)n * M.K + k) * 3,
-                add3(ld3(xp + 3 * b), rotate(ld3(M.site_pos + 3 * k), ld4(xq + 4 * b))));
+            st3(site_xpos + ((size_t)n0 * K + e) * 3,
+                add3(ld3(rows_p + row * SP + 3 * b), rotate(ld3(M.site_pos + 3 * k), ld4(rows_q + row * SQ + 4 * b))));
+            k += 64;
+            while (k >= K) { k -= K; ++row; }
         }
     }
 }
@@ -1505,7 +1576,15 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fk_kernel, dim3((N + 63) / 64), dim3(64), 0, s, M, qpos, N, qn, xpos, xquat, site_xpos, normalize);
+    // poses per workgroup: a power of two whose rows fit a fifth of a CU's LDS next to the tables (rodent: 16, five workgroups
+    // per CU; the mouse's 6.3 KB per pose: 4) -- the lanes' serial walks need all the wavefronts a CU can hold
+    int pb = 64;
+    while (pb > 1 && (size_t)fk_lds_layout(M.nbody, M.njnt, M.nq, pb).total * sizeof(float) > 32 * 1024) pb >>= 1;
+    const size_t lds_bytes = (size_t)fk_lds_layout(M.nbody, M.njnt, M.nq, pb).total * sizeof(float);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;  // (a single pose of more than 5 000 bodies)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fk_kernel, dim3((N + pb - 1) / pb), dim3(64), lds_bytes, s, M, qpos, N, qn, xpos, xquat, site_xpos, normalize, pb);
     return hipGetLastError();
 }
 

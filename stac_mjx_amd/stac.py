@@ -47,6 +47,8 @@ class Stac:
                              lm_maxiter=int(stac_cfg.get("lm_maxiter", 20) or 20))
         self.stac_core_obj = StacCore(self.engine, float(cfg.model.FTOL), int(cfg.model.N_ITER_Q))
         self._offsets = torch.as_tensor(s.tables.site_pos.copy())
+        self.timings = None  # bench.py --mode run: {} collects the phase times of ik_only (see _tick)
+        self._t_last = 0.0
         self._timestep = s.tables.timestep
 
     # -- helpers ------------------------------------------------------------------------------------
@@ -141,21 +143,41 @@ class Stac:
     def ik_only(self, kp_data, offsets) -> StacData:
         """Inverse kinematics with fixed offsets; clips are independent chains, sharded over ranks."""
         eng = self.engine
+        tick = self._tick
+        tick(None)
         batched = utils.batch_kp_data(np.asarray(kp_data, dtype=np.float32), int(self.cfg.stac.n_frames_per_clip),
                                       continuous=bool(self.cfg.stac.continuous))
         eng.set_site_pos(torch.as_tensor(np.asarray(offsets, dtype=np.float32)).reshape(-1, 3))
         n_clips = batched.shape[0]
         lo, hi = dist.shard_range(n_clips)
         kp = torch.as_tensor(batched[lo:hi]).to(eng.device)
+        tick("batch_and_h2d_s")
         if self._root_kp_idx == -1:
             self._log("Missing or invalid ROOT_OPTIMIZATION_KEYPOINT, skipping root_optimization()")
         res = self._q_phase(kp, do_root_opt=self.setup.do_root_opt)
+        tick("q_phase_and_fk_kernels_s")
         if dist.is_dist():
             res, batched = self._gather(res, batched, n_clips, lo, hi)
+            tick("gather_s")
         _, mean, std = self._get_error_stats(res["frame_error"].cpu().numpy())
         self._log(f"Mean: {mean}\nStandard deviation: {std}")
         self._offsets = eng.get_site_pos()
-        return self._package_data(res, batched, batched=True)
+        data = self._package_data(res, batched, batched=True)
+        tick("d2h_and_packing_s")
+        return data
+
+    def _tick(self, name):
+        """Phase clock of ik_only for `bench.py --mode run` (``self.timings = {}`` switches it on; it synchronises the device
+        at every phase boundary, so it is off by default)."""
+        if self.timings is None:
+            return
+        import time
+
+        torch.cuda.synchronize(self.engine.device)
+        now = time.perf_counter()
+        if name is not None:
+            self.timings[name] = self.timings.get(name, 0.0) + now - self._t_last
+        self._t_last = now
 
     def _gather(self, res, kp_clips, n_clips, lo, hi):
         """Multi-GPU result placement, ``stac.gather`` (engine extension): "rank0" (default) -- rank 0 packages every
