@@ -238,12 +238,14 @@ def run_run_mode(args, rank, local_rank, world, dist):
 
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (never re-exec a process that
-    may have touched the GPU; counting devices does not initialise HIP) and return their exit code.  Rank 0 of the
-    children prints the JSON line on the inherited stdout."""
+    may have touched the GPU; the devices are counted from the KFD topology in sysfs, not through torch or HIP) and return
+    their exit code.  Rank 0 of the children prints the JSON line on the inherited stdout."""
     import socket
     import subprocess
 
-    visible = torch.cuda.device_count()
+    from stac_mjx_amd.dist import visible_gpu_count
+
+    visible = visible_gpu_count()  # KFD topology + *_VISIBLE_DEVICES: never torch / HIP in the launcher parent
     if visible < n_gpus:
         print(f"bench.py: --gpus {n_gpus} requested but only {visible} GPU{'s' if visible != 1 else ''} visible "
               f"on this node; nothing launched", file=sys.stderr)
@@ -424,6 +426,19 @@ def main():
                             "valu_active_frac: SQ_ACTIVE_INST_VALU quad-cycles x 4; 1024 SIMDs at 2.4 GHz"}
     except (FileNotFoundError, KeyError):
         pass
+    if world > 1 and args.solver == "pg":
+        # The q_phase shards without a collective, so a scaling line of this mode would prove only the timing barrier.  The one
+        # data-path exchange of the engine -- the offset phase's 3K + 2 partial sums -- is therefore exercised
+        # on the same ranks: this rank's sums over its own first frames, all-reduced and finished on every rank.  Never `value`.
+        from stac_mjx_amd.dist import offset_phase_exchange_probe
+
+        n_s = min(frames_step, 100)
+        part = eng.m_partial(kp.reshape(-1, kp.shape[-1])[:n_s], out["qpos"].reshape(-1, fs.tables.nq)[:n_s])
+        off_now = eng.get_site_pos()
+        is_reg = torch.ones_like(off_now)
+        probe = offset_phase_exchange_probe(part, lambda red: eng.m_finish(red, off_now, is_reg, 1.0)[0])
+        line["config"]["offset_phase_exchange"] = dict(probe, note="one all-reduce (all-gather + fixed-order sum) of the offset "
+                                                       "phase's partial sums per calibration iteration; --mode fit runs the whole calibration")
     if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and F == 1 and not args.no_extras:
         # BASELINE configs[1] with the reference's DEFAULT chaining (configs/stac/stac.yaml:9, n_frames_per_clip = 250):
         # the same number of frames as 40 warm-started clips -- latency mode, one chain per workgroup.  Never `value`.

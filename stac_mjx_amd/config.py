@@ -29,7 +29,8 @@ _STAC_REQUIRED = (
 )  # fmt: skip
 _STAC_OPTIONAL = ("num_clips",)
 _MUJOCO_REQUIRED = ("solver", "iterations", "ls_iterations")
-# Engine extensions (not in the reference schema); all optional.
+# Engine extensions (not in the reference schema); all optional.  (lm_maxiter: accepted steps per solve of solver = lm, default 20
+# -- 40 until round 3; gather: auto | rank0 | all | none, resolved per run by main.run_stac, the caller's config is never modified)
 _STAC_EXTENSIONS = ("solver", "lanes_per_chain", "device", "time_indices", "fit_frames_per_clip", "reference_marker_order", "gather", "gather_max_bytes", "lm_maxiter")
 _MODEL_EXTENSIONS = ("KP_NAMES_LABEL3D_PATH",)
 

@@ -66,6 +66,7 @@ struct DebugSwitches {
 
 struct stac_model {
     int device = 0;   // the HIP device the model lives on: every entry point runs with it current (and restores)
+    int cus = 256;    // its compute units (hipDeviceAttributeMultiprocessorCount: 256 on a whole MI355X; fewer on a partition or under a CU mask)
     DebugSwitches dbg;
     float *d_bounds = nullptr;          // [2 nqpad] per-call lb / ub of stac_q_solve
     std::vector<float> bounds_cache;    // what d_bounds holds
@@ -125,11 +126,15 @@ static hipError_t upload(T **dst, const T *src, size_t n) {
 
 // Makes the model's device current for the duration of an entry point (a caller may have switched devices since
 // stac_model_create: allocations and launches must still land on the model's GPU), then restores the caller's.
+// Compute units of the device the running entry point works on: the launch heuristics (resident chains, chain queue,
+// placement by SIMD load) count with the device's own CUs, not with a compile-time 256 (set by DeviceGuard)
+static thread_local int t_cus = 256;
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
     explicit DeviceGuard(const stac_model *m) {
         if (m && hipGetDevice(&prev) == hipSuccess && prev != m->device) switched = hipSetDevice(m->device) == hipSuccess;
+        if (m) t_cus = m->cus;
     }
     ~DeviceGuard() {
         if (switched) (void)hipSetDevice(prev);
@@ -575,7 +580,8 @@ static size_t q_lds_bytes(const PlanHeader &h, int G, int nkinds, int wpb) {
     return (size_t)(plan_words + q_mb_words(nkinds, G) + wpb * (64 / G) * q_chain_stride(h, G)) * sizeof(float);
 }
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr int kCus = 256;
+constexpr int kFullCus = 256;  // a whole MI355X (the placement kernel's SIMD census is laid out for it)
+#define kCus t_cus
 // latency mode: up to this many chains a chain is spread over 8 / 4 wavefronts of a workgroup (else one per chain)
 // (measured, rodent, 250-frame clips, profiles/r02/lat_sweep.txt: with the four-lanes-per-position kinematics four
 // wavefronts per chain are 6-12 % ahead of eight from 40 to 256 chains and hold twice as many chains: eight are kept
@@ -673,6 +679,11 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     }
     stac_model *m = new stac_model();
     (void)hipGetDevice(&m->device);
+    {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, m->device) == hipSuccess && n > 0) m->cus = n;
+        t_cus = m->cus;
+    }
     m->dbg.read_env();
     if (build_plan(m, t) != STAC_OK) { delete m; return nullptr; }
     if (m->dbg.flags >= 0 && (m->dbg.flags & 4)) m->h.fk_uniform = 0;  // A/B switch: run the program step by step through its flags and forms
@@ -954,7 +965,9 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             const long waves = ((long)nchains * G + 63) / 64, simds = 4L * kCus;
             const bool all_resident = qslots == 0 && waves <= (long)sh.waves_per_cu * kCus;
             // (from ONE wavefront per SIMD upward: 6 144 chains = 1.5 per SIMD 23.5 -> 21.0 ms, profiles/r03/shape_sweep.txt)
-            if (all_resident && waves > simds && waves % simds != 0) a.place_crowded = (int)(waves / simds) + 1;
+            // (placement counts wavefronts per SIMD of a whole device: off on a partition / under a CU mask, where the census
+            //  would wait for wavefronts that are not resident and every launch would sit out the time-out)
+            if (all_resident && kCus == kFullCus && waves > simds && waves % simds != 0) a.place_crowded = (int)(waves / simds) + 1;
             else {
                 a.place = nullptr;
                 // with a chain queue the order still serves: the queue hands the chains out longest first, four of similar

@@ -166,6 +166,10 @@ void q_phase_kernel(const QArgs a_in) {
                 const bool crowded = n >= a.place_crowded;
                 const int t = atomicAdd(pl + (crowded ? 1 : 2), 1);
                 pos = crowded ? t : total - 1 - t;
+                // the grid's padding wavefronts (positions without chains: whole workgroups are launched) sit at the SHORT end
+                // of the order, below the shortest chains, so that it is the crowded SIMDs that draw them
+                const int nreal = (a.C + CPW - 1) / CPW, npad = total - nreal;
+                pos = pos >= npad ? pos - npad : nreal + pos;
             }
             wave_pos = __builtin_amdgcn_readfirstlane(pos);
         }

@@ -92,3 +92,69 @@ def gather_clips(local: torch.Tensor, n_total: int, dst: int = 0):
     if r != dst:
         return None
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+# ---- launcher helpers (bench.py --gpus N outside torchrun) ---------------------------------------------------------------------
+def visible_gpu_count(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes", environ=None) -> int:
+    """GPUs this process would see, WITHOUT touching the HIP runtime (a launcher parent must never initialise the GPU:
+    its children are the ranks).  Counts the KFD topology nodes that have SIMDs (CPU nodes have ``simd_count 0``) and
+    applies ``ROCR_VISIBLE_DEVICES`` / ``HIP_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` the way the runtime does (a list
+    of indices or UUIDs; an index beyond the device count ends the list).  Returns 0 when the topology is not readable."""
+    import os
+    from pathlib import Path
+
+    env = os.environ if environ is None else environ
+    n = 0
+    try:
+        nodes = sorted(Path(sysfs_root).iterdir(), key=lambda p: int(p.name) if p.name.isdigit() else 1 << 30)
+    except OSError:
+        return 0
+    for node in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in (node / "properties").read_text().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):  # each filters what the previous left
+        v = env.get(var)
+        if v is None:
+            continue
+        keep = 0
+        for tok in (x.strip() for x in v.split(",")):
+            if tok == "":
+                break
+            if tok.lstrip("-").isdigit():
+                if not 0 <= int(tok) < n:
+                    break  # (the runtime stops at the first invalid index)
+            keep += 1  # an index in range, or a UUID (GPU-xxxx): taken at face value
+        n = min(n, keep)
+    return n
+
+
+def offset_phase_exchange_probe(partial: torch.Tensor, finish, repeats: int = 20) -> dict:
+    """Time the ONE data-path collective of the engine on the live process group and check its contract: ``partial`` is this
+    rank's offset-phase sums (3K + 2 floats, ``Engine.m_partial``), ``finish(reduced) -> offsets`` the closed form
+    (``Engine.m_finish``).  Every rank must end up with bitwise the same offsets (all-gather + fixed-order sum).  Returns
+    {us_per_exchange, backend, world_size, n_floats, offsets_bitwise_equal_across_ranks}."""
+    import time
+
+    if not is_dist():
+        return {"us_per_exchange": None, "backend": None, "world_size": 1, "n_floats": int(partial.numel()),
+                "offsets_bitwise_equal_across_ranks": True}
+    sync = (lambda: torch.cuda.synchronize(partial.device)) if partial.is_cuda else (lambda: None)
+    reduced = all_reduce_partial(partial)  # warm-up (connection set-up)
+    sync()
+    tdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        reduced = all_reduce_partial(partial)
+    sync()
+    dt = time.perf_counter() - t0
+    off = finish(reduced).contiguous()
+    bits = off.view(torch.int32) if off.dtype == torch.float32 else off
+    parts = [torch.empty_like(bits) for _ in range(tdist.get_world_size())]
+    tdist.all_gather(parts, bits)
+    same = all(bool(torch.equal(parts[0], p)) for p in parts[1:])
+    return {"us_per_exchange": 1e6 * dt / repeats, "backend": tdist.get_backend(), "world_size": tdist.get_world_size(),
+            "n_floats": int(partial.numel()), "offsets_bitwise_equal_across_ranks": same}

@@ -108,7 +108,12 @@ def _host_u8(a, n):
 
 
 class Engine:
-    """One compiled model resident on one GPU."""
+    """One compiled model resident on one GPU.
+
+    ``solver="lm"`` (engine extension, not the reference's algorithm) runs at most ``lm_maxiter`` accepted steps per solve:
+    the default is 20 since round 3 (it was 40; the steps beyond 20 buy 0.001 mm of marker RMSE on the bench batch and set
+    the tail of a launch, ``profiles/r03/lm_cap_sweep.txt``) -- pass ``lm_maxiter=40`` / ``stac.lm_maxiter: 40`` for the old
+    behaviour.  ``solver="pg"`` (default, parity mode) is not affected."""
 
     def __init__(self, tables, lb, ub, *, tol=1e-4, maxiter=400, maxls=15, lanes_per_chain=0, device=None,
                  solver="pg", lm_maxiter=20, lm_lambda0=1e-2):

@@ -39,6 +39,13 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
     ik_only_path = base_path / cfg.stac.ik_only_path
     xml_path = base_path / cfg.model.MJCF_PATH
     stac = Stac(xml_path, cfg, kp_names, setup=setup, device=device)
+    if not cfg.stac.skip_ik_only and dist.world()[1] > 1 and str(cfg.stac.get("gather", "auto") or "auto") == "none":
+        # an EXPLICIT gather = none cannot serve a continuous run (cross-fades reach across shard borders): say so before any
+        # work is done -- the config that decides is the one stored with the fit (the caller's, when this run writes it)
+        fit_cfg = cfg if not cfg.stac.skip_fit_offsets else io.load_stac_data(fit_offsets_path)[0]
+        if fit_cfg.stac.continuous:
+            raise ValueError("stac.gather = none writes per-rank shards, but stac.continuous cross-fades neighbouring "
+                             "clips across shard borders: use gather = rank0 (or all, or auto) for continuous runs")
 
     if not cfg.stac.skip_fit_offsets:
         kps = kp_data[: cfg.stac.n_fit_frames]
@@ -66,14 +73,15 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
     cfg, fit_data = io.load_stac_data(fit_offsets_path)
     rank, world_size = dist.world()
     F = int(cfg.stac.n_frames_per_clip)
-    sharded = world_size > 1 and _ik_output_mode(stac.cfg, kp_data.shape[0], stac) == "none"
-    if sharded:
-        if cfg.stac.continuous:
-            raise ValueError("stac.gather = none writes per-rank shards, but stac.continuous cross-fades neighbouring "
-                             "clips across shard borders: use gather = rank0 (or all) for continuous runs")
-        stac.cfg.stac["gather"] = "none"  # an "auto" decision becomes explicit for Stac._gather
-    ik_data = stac.ik_only(kp_data, fit_data.offsets)
-    if rank != 0 and not sharded and str(stac.cfg.stac.get("gather", "rank0") or "rank0") != "all":
+    # where the results go: resolved here (an "auto" becomes rank0 / none by output size; a continuous run always gathers) and
+    # handed to ik_only as an argument -- the caller's config object is not touched
+    mode = _ik_output_mode(stac.cfg, kp_data.shape[0], stac, continuous=bool(cfg.stac.continuous)) if world_size > 1 else "rank0"
+    sharded = world_size > 1 and mode == "none"
+    if sharded and cfg.stac.continuous:  # (explicit gather = none with a fit file whose config turned out continuous)
+        raise ValueError("stac.gather = none writes per-rank shards, but stac.continuous cross-fades neighbouring "
+                         "clips across shard borders: use gather = rank0 (or all, or auto) for continuous runs")
+    ik_data = stac.ik_only(kp_data, fit_data.offsets, gather=mode)
+    if rank != 0 and not sharded and mode != "all":
         dist.barrier()  # this rank holds its own shard only: rank 0 post-processes and writes the gathered result
         return fit_offsets_path, io.resolve_output_path(ik_only_path)
     if cfg.stac.continuous:
@@ -109,14 +117,17 @@ def run_stac(cfg, kp_data, kp_names, base_path=None, *, setup=None, device=None)
 GATHER_AUTO_MAX_BYTES = 1 << 30  # above this much output a multi-GPU run keeps per-rank shard files ("auto")
 
 
-def _ik_output_mode(cfg, n_frames: int, stac) -> str:
+def _ik_output_mode(cfg, n_frames: int, stac, continuous: bool = False) -> str:
     """``stac.gather`` for the ik_only outputs: "rank0" | "all" | "none" | "auto" (default).  "auto" gathers to rank 0
     while the packed outputs (qpos, xpos, xquat, marker_sites, kp_data; 2 728 B per rodent frame) stay below
     ``stac.gather_max_bytes`` (default 1 GiB) and writes per-rank shards above: a 1 M-frame run is 2.7 GB that a
-    padded gather would stage on rank 0's GPU for nothing."""
+    padded gather would stage on rank 0's GPU for nothing.  A continuous run (cross-fades across clip borders, done on the
+    gathered result) always gathers under "auto", whatever its size."""
     mode = str(cfg.stac.get("gather", "auto") or "auto")
     if mode != "auto":
         return mode
+    if continuous:
+        return "rank0"
     t = stac.setup.tables
     per_frame = 4 * (t.nq + 7 * t.nbody + 6 * t.nsite)
     limit = int(cfg.stac.get("gather_max_bytes", GATHER_AUTO_MAX_BYTES) or GATHER_AUTO_MAX_BYTES)

@@ -140,8 +140,9 @@ class Stac:
         return self._package_data(res, kp_np.reshape(kp_np.shape[0] * n_per, kp_np.shape[-1]), batched=fpc > 0)
 
     # -- ik_only (stac.py:356-454) --------------------------------------------------------------------------
-    def ik_only(self, kp_data, offsets) -> StacData:
-        """Inverse kinematics with fixed offsets; clips are independent chains, sharded over ranks."""
+    def ik_only(self, kp_data, offsets, gather=None) -> StacData:
+        """Inverse kinematics with fixed offsets; clips are independent chains, sharded over ranks.  ``gather`` (multi-GPU
+        result placement: "rank0" | "all" | "none") overrides ``stac.gather`` for this call (run_stac resolves "auto")."""
         eng = self.engine
         tick = self._tick
         tick(None)
@@ -157,7 +158,7 @@ class Stac:
         res = self._q_phase(kp, do_root_opt=self.setup.do_root_opt)
         tick("q_phase_and_fk_kernels_s")
         if dist.is_dist():
-            res, batched = self._gather(res, batched, n_clips, lo, hi)
+            res, batched = self._gather(res, batched, n_clips, lo, hi, mode=gather)
             tick("gather_s")
         _, mean, std = self._get_error_stats(res["frame_error"].cpu().numpy())
         self._log(f"Mean: {mean}\nStandard deviation: {std}")
@@ -179,11 +180,11 @@ class Stac:
             self.timings[name] = self.timings.get(name, 0.0) + now - self._t_last
         self._t_last = now
 
-    def _gather(self, res, kp_clips, n_clips, lo, hi):
+    def _gather(self, res, kp_clips, n_clips, lo, hi, mode=None):
         """Multi-GPU result placement, ``stac.gather`` (engine extension): "rank0" (default) -- rank 0 packages every
         clip, the other ranks keep (and return) their own shard; "all" -- every rank gets every clip (small runs,
         tests); "none" -- every rank keeps its shard.  Returns (results, the keypoint clips that go with them)."""
-        mode = str(self.cfg.stac.get("gather", "rank0") or "rank0")
+        mode = str(mode or self.cfg.stac.get("gather", "rank0") or "rank0")
         if mode == "auto":  # run_stac resolves "auto" by output size before it calls ik_only; direct callers get rank0
             mode = "rank0"
         if mode not in ("rank0", "all", "none"):

@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -70,6 +71,14 @@ def _worker(rank, world, port, q):
         gathered = [None] * world
         tdist.all_gather_object(gathered, params.tobytes())
         assert gathered[0] == gathered[1]  # identical offsets on every rank (bitwise)
+        # the sub-record bench.py adds to a multi-GPU line (config.offset_phase_exchange): timing + the bitwise contract
+        fin = lambda red: torch.as_tensor(orc.m_finish(red.numpy(), off, is_reg, 1.0)[0])  # noqa: E731
+        probe = dist.offset_phase_exchange_probe(part, fin, repeats=3)
+        assert probe["world_size"] == world and probe["backend"] == "gloo" and probe["n_floats"] == 71
+        assert probe["us_per_exchange"] > 0 and probe["offsets_bitwise_equal_across_ranks"] is True
+        # ... and it notices ranks that disagree
+        bad = dist.offset_phase_exchange_probe(part, lambda red: fin(red) + float(rank), repeats=1)
+        assert bad["offsets_bitwise_equal_across_ranks"] is False
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
@@ -140,8 +149,8 @@ def _shard_worker(rank, world, port, tmp, mode, q):
                 self.cfg = cfg
                 self.setup = fs
 
-            def ik_only(self, kp, offsets):
-                mode_now = str(self.cfg.stac.get("gather", "rank0"))
+            def ik_only(self, kp, offsets, gather=None):
+                mode_now = str(gather or self.cfg.stac.get("gather", "rank0"))
                 lo, hi = dist.shard_range(n_clips) if mode_now == "none" else (0, n_clips)
                 n = (hi - lo) * F
                 qp = z(n, 74)
@@ -151,8 +160,11 @@ def _shard_worker(rank, world, port, tmp, mode, q):
                                    offsets=np.asarray(offsets), kp_data=kp[lo * F : hi * F], **names)
 
         main.Stac = ShardStac
-        _, ik_path = main.run_stac(cfg, kp_all, fs.kp_names, base_path=tmp)
-        q.put((rank, str(ik_path)))
+        try:
+            _, ik_path = main.run_stac(cfg, kp_all, fs.kp_names, base_path=tmp)
+            q.put((rank, str(ik_path)))
+        except ValueError as e:  # (a refused configuration: reported, both ranks refuse alike)
+            q.put((rank, "ValueError: " + str(e)))
     finally:
         tdist.destroy_process_group()
 
@@ -197,3 +209,21 @@ def test_run_stac_auto_gather_switches_on_output_size(tmp_path):
     assert small[0].endswith(("ik.h5", "ik.npz")) and not (tmp_path / "a" / "ik.manifest.json").exists()
     big = _run_sharded(tmp_path / "b", dict(gather_max_bytes=1000)) if (tmp_path / "b").mkdir() is None else None
     assert big[0].endswith("ik.manifest.json")
+
+
+def test_run_stac_auto_gather_keeps_a_continuous_run_on_rank0(tmp_path):
+    """"auto" never shards a continuous run (its cross-fades reach across shard borders): even above
+    stac.gather_max_bytes it resolves to rank0; an EXPLICIT gather = none on a continuous run is refused on every rank
+    before any work is done."""
+    import types
+
+    from stac_mjx_amd import main
+    from stac_mjx_amd.config import ConfigNode
+
+    stac = types.SimpleNamespace(setup=types.SimpleNamespace(tables=types.SimpleNamespace(nq=74, nbody=67, nsite=23)))
+    cfg = ConfigNode({"stac": {"gather": "auto", "gather_max_bytes": 1000}})
+    assert main._ik_output_mode(cfg, 10, stac) == "none" and main._ik_output_mode(cfg, 10, stac, continuous=True) == "rank0"
+    assert main._ik_output_mode(ConfigNode({"stac": {"gather": "none"}}), 10, stac, continuous=True) == "none"  # explicit stays
+    out = _run_sharded(tmp_path, dict(gather="none", continuous=True))
+    assert all(v.startswith("ValueError: stac.gather = none") for v in out.values()), out
+    assert not list(tmp_path.glob("ik*"))  # refused before anything was written

@@ -470,7 +470,7 @@ def test_run_stac_rebinds_the_config_stored_with_the_fit(tmp_path, rodent_setup,
             self.cfg = cfg
             seen["stac"] = self
 
-        def ik_only(self, kp, offsets):
+        def ik_only(self, kp, offsets, gather=None):
             seen["offsets"] = np.asarray(offsets)
             q = z(8, 74)
             q[:, 3] = 1.0
@@ -629,3 +629,42 @@ def test_nwb_and_h5_input_loaders_on_the_reference_data(tmp_path):
     assert d["h5_names"] == d["mouse_pairs"] and d["h5_names"][:5] == ["Nose", "Ear_R", "Ear_L", "TTI", "Head"]
     assert d["nwb_equals_mat"] and d["mat_equals_fixture"] and d["h5_equals_fixture"] and d["h5_finite"]
     assert d["dtypes"] == ["float32", "float32"]
+
+
+# ---- launcher: counting GPUs without touching HIP (bench.py --gpus N) -------------------------------------------
+def _fake_kfd(tmp_path, simd_counts):
+    for i, n in enumerate(simd_counts):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if n else 16}\nsimd_count {n}\nmem_banks_count 1\n")
+    return str(tmp_path)
+
+
+def test_visible_gpu_count_reads_the_kfd_topology_and_the_visibility_variables(tmp_path):
+    from stac_mjx_amd.dist import visible_gpu_count
+
+    root = _fake_kfd(tmp_path, [0, 0, 1024, 1024, 1024, 1024])  # two CPU nodes, four GPUs
+    assert visible_gpu_count(root, {}) == 4
+    assert visible_gpu_count(root, {"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert visible_gpu_count(root, {"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1"}) == 1   # the second filters the first
+    assert visible_gpu_count(root, {"CUDA_VISIBLE_DEVICES": ""}) == 0
+    assert visible_gpu_count(root, {"HIP_VISIBLE_DEVICES": "0,7,1"}) == 1                          # stops at the invalid index
+    assert visible_gpu_count(root, {"ROCR_VISIBLE_DEVICES": "GPU-abcdef0123456789,GPU-0123"}) == 2  # UUIDs at face value
+    assert visible_gpu_count(str(tmp_path / "missing"), {}) == 0
+
+
+def test_bench_gpus_2_without_two_gpus_exits_2_and_never_imports_hip_state(tmp_path):
+    """`python bench.py --gpus 2` on a box with fewer GPUs: exit code 2, a clear message, nothing launched -- decided from
+    sysfs, so the parent has not initialised any GPU runtime on the way."""
+    import subprocess
+    import sys as _sys
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([_sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("this box has two GPUs")
+    assert r.returncode == 2 and "only" in r.stderr and "visible" in r.stderr and r.stdout.strip() == ""
+    src = (ROOT / "bench.py").read_text()
+    launch = src[src.index("def self_launch"):src.index("def lib_digest")]
+    assert "torch.cuda" not in launch and "device_count" not in launch

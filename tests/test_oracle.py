@@ -319,7 +319,7 @@ def test_pg_residuals_against_the_run_the_reference_printed(orc, rodent_setup, r
     fs = rodent_setup
     kp = rodent_mocap[:10]
     q, st = orc.root_optimization(kp, fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
-    assert st["iter_num"] == 30 and abs(st["error"] - 9.50e-5) < 1e-6  # reference printed 4.31e-05: unexplained factor 2.2
+    assert st["error"] <= 1e-4  # converged, like the reference's (whose value the restatement does not reach: next test)
     out = orc.pose_optimization(kp, q, fs.lb, fs.ub, fs.part_masks)
     e = out["frame_error"].astype(np.float64)
     assert (e <= 1e-4).all()  # every frame's last (head) solve converged, like the reference's
@@ -329,6 +329,24 @@ def test_pg_residuals_against_the_run_the_reference_printed(orc, rodent_setup, r
     # frames 1-9: mean within 5 %, std within 25 % of the notebook's ten-frame figures
     assert abs(e[1:].mean() / 3.5538e-05 - 1) <= 0.05, e[1:].mean()
     assert abs(e[1:].std() / 9.482e-06 - 1) <= 0.25, e[1:].std()
+
+
+@pytest.mark.xfail(strict=True, reason="KNOWN GAP, not a target: the reference notebook printed a root-optimisation residual of "
+                   "4.3102e-05; the restated PG stops at 9.50e-05 after 30 iterations of the second root solve (factor 2.2, unexplained "
+                   "by 70 variants: profiles/r03/jaxopt_variant_sweep.txt).  A change that moves the oracle ONTO the reference makes "
+                   "this test pass -- then delete the marker")
+def test_known_gap_root_residual_of_the_printed_reference_run(orc, rodent_setup, rodent_mocap):
+    fs = rodent_setup
+    _, st = orc.root_optimization(rodent_mocap[:10], fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
+    assert abs(st["error"] / 4.3102e-05 - 1) <= 0.05, (st["iter_num"], st["error"])
+
+
+def test_regression_root_solve_trajectory_of_the_restatement(orc, rodent_setup, rodent_mocap):
+    """Regression pin of the restatement's OWN trajectory (so that an unintended change of the oracle is noticed); this
+    value is NOT the reference's -- see the known-gap test above."""
+    fs = rodent_setup
+    _, st = orc.root_optimization(rodent_mocap[:10], fs.tables.qpos0, fs.lb, fs.ub, fs.trunk_kps, fs.root_kp_idx)
+    assert st["iter_num"] == 30 and abs(st["error"] - 9.50e-5) < 1e-6
 
 
 def test_variant_sweep_baseline_equals_oracle(orc, rodent_setup, rodent_mocap):
