@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3
+VALU_ISSUE_CEILING = 0.429  # wave64 VALU instructions per cycle per SIMD, measured (profiles/tools/valu_issue_micro.hip)
 
 
 def load_setup(model="rodent"):
@@ -417,13 +418,15 @@ def main():
                     "logical_evaluations_per_step": evals, "lane_slots_per_evaluation": lane_slots / evals,
                     "algorithmic_flops_per_step": flops, "algorithmic_flop_per_lane_slot": flops / lane_slots,
                     "useful_lane_fraction": (flops / 2.0) / lane_slots,  # one FMA = 2 flop per lane-slot at best
-                    "valu_issue_busy_frac": ent["sq_insts_valu"] * 2.0 / (1024 * 2.4e9 * kern_ms * 1e-3),
-                    # what the hardware counts: SQ_ACTIVE_INST_VALU is in quad-cycles (MI355X_MICROARCH.md, s_memtime row) and comes out
-                    # at one per VALU instruction here, i.e. 4 cycles of a SIMD's vector pipe each -- the figure that explains why a
-                    # SIMD with three wavefronts of this kernel runs them a quarter slower than one with two (placement)
-                    "valu_active_frac": (ent["sq_active_inst_valu"] * 4.0 / (1024 * 2.4e9 * kern_ms * 1e-3)) if ent.get("sq_active_inst_valu") else None,
-                    "note": "valu_issue_busy_frac: wave64 VALU instruction = 2 issue cycles on a SIMD-32 (the guide's throughput figure); "
-                            "valu_active_frac: SQ_ACTIVE_INST_VALU quad-cycles x 4; 1024 SIMDs at 2.4 GHz"}
+                    # ONE busy figure: issued wave64 VALU instructions against what the SIMDs can issue -- the measured ceiling
+                    # of 0.429 instructions per cycle and SIMD (2.33 cycles each; profiles/tools/valu_issue_micro.hip,
+                    # profiles/r04/valu_issue_micro.txt: eight independent v_fma_f32 chains at 2-4 wavefronts per SIMD; a lone
+                    # wavefront issues one per 4.58 cycles whatever its dependences), 1024 SIMDs at the nominal 2.4 GHz
+                    "valu_issue_busy_frac": ent["sq_insts_valu"] / (VALU_ISSUE_CEILING * 1024 * 2.4e9 * kern_ms * 1e-3),
+                    "valu_issue_ceiling_insts_per_cycle_per_simd": VALU_ISSUE_CEILING,
+                    "sq_active_inst_valu_raw": ent.get("sq_active_inst_valu"),  # raw counter (quad-cycles), not a busy figure
+                    "note": "valu_issue_busy_frac = SQ_INSTS_VALU / (0.429 x SIMD-cycles of the launch): 1.0 = every SIMD issuing "
+                            "VALU back to back from several wavefronts"}
     except (FileNotFoundError, KeyError):
         pass
     if world > 1 and args.solver == "pg":
