@@ -15,8 +15,13 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libstac_hip.so"
 SOURCES = [CSRC / "stac_kernels.hip", CSRC / "stac_lm.hip", CSRC / "stac_abi.hip"]
 HEADERS = [CSRC / "stac_plan.hpp", CSRC / "stac_device.hpp", CSRC.parents[1] / "include" / "stac_hip.h"]
+# -amdgpu-opt-vgpr-liverange=false: SIOptimizeVGPRLiveRange is the pass behind round 3's stale-state defect (a latency-kernel
+# shape whose results depended on what the previous launch left in registers / scratch): with it off that shape is correct under
+# every poison pattern, with it on it is wrong on 36 of 36 models (profiles/r04/stale_spill_repro.txt, reproducer:
+# tests/tools/repro_stale_spill/).  Costs nothing on the throughput bench, 2 % on 250-frame clips.
+# -amdgpu-sched-strategy=max-memory-clause: LDS reads grouped ahead of their uses, +1.5 ... 2 % (profiles/r03/flag_sweep.txt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-fno-slp-vectorize",
-         "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
+         "-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", "-amdgpu-opt-vgpr-liverange=false"]
 FLAGS += os.environ.get("STAC_HIP_EXTRA_FLAGS", "").split()
 
 
