@@ -36,8 +36,15 @@ done
   run "LM 40 clips x 250" --solver lm --frames-per-clip 250 --steps 2 --warmup 1
   run "fit mode, 1000 frames as 100 clips" --mode fit --frames 1000 --frames-per-clip 10 --steps 3 --warmup 1
   run "fit mode, one chain of 1000 frames (reference sequencing, config 3)" --mode fit --frames 1000 --frames-per-clip 1000 --steps 1 --warmup 0
+  run "run mode: Stac.ik_only end to end, 100k frames at 250 per clip, all outputs + result file" --mode run --frames 100000 --frames-per-clip 250 --steps 2 --warmup 1
   echo "]"
 } > $OUT/secondary.json
+# the FK output pass on its own: rocprofv3 kernel stats of a run-mode bench (fk_kernel's line: duration against 2 744 B per pose)
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp_run && rocprofv3 --kernel-trace --stats -d /tmp/rp_run --output-format csv -- python3 $R/bench.py --mode run --frames 100000 --frames-per-clip 250 --steps 1 --warmup 0 > /tmp/rp_run.log 2>&1; f=$(find /tmp/rp_run -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/run_kernel_stats.csv )
+# VALU issue ceiling (micro-benchmark) and the kernel coverage of the GPU suite
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 profiles/tools/valu_issue_micro.hip -o /tmp/valu_issue_micro && /tmp/valu_issue_micro > $OUT/valu_issue_micro.txt 2>&1
+bash profiles/tools/suite_coverage.sh > $OUT/suite_coverage.log 2>&1
+grep -v "at::native\|__amd_rocclr\|^ *[0-9]* *$" gpurun_out/gpu_suite_kernels.txt > $OUT/gpu_suite_kernels.txt
 python3 profiles/tools/lat_sweep.py > $OUT/lat_sweep.txt 2>&1
 python3 profiles/tools/lat_sweep.py fly 100 40 256 500 1000 2000 > $OUT/lat_sweep_fly.txt 2>&1
 python3 profiles/tools/lat_sweep.py mouse 20 40 256 500 1000 > $OUT/lat_sweep_mouse.txt 2>&1

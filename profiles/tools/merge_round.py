@@ -47,7 +47,8 @@ def main():
                        f"library build {digest[:16]}")
         (dst / f"{tag}{leg}_pmc.json").write_text(json.dumps(pm, indent=1) + "\n")
         per[leg] = pm
-    for f in ("secondary.json", "lat_sweep.txt", "lat_sweep_fly.txt", "lat_sweep_mouse.txt"):
+    for f in ("secondary.json", "lat_sweep.txt", "lat_sweep_fly.txt", "lat_sweep_mouse.txt", "run_kernel_stats.csv", "valu_issue_micro.txt",
+              "gpu_suite_kernels.txt"):
         if (src / f).exists():
             shutil.copy(src / f, dst / f)
 
