@@ -190,10 +190,10 @@ def run_run_mode(args, rank, local_rank, world, dist):
     kp = torch.as_tensor(kp_host).to(eng.device)
     kw = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=max(fs.root_kp_idx, 0), root_dims=fs.root_dims,
               do_root_opt=fs.do_root_opt)
-    res = eng.q_phase(kp, want_bodies=False, want_markers=False, **kw)
+    res = eng.q_phase(kp, want_bodies=False, want_markers=False, want_carry=False, **kw)
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     e[0].record()
-    res = eng.q_phase(kp, want_bodies=False, want_markers=False, out=res, **kw)
+    res = eng.q_phase(kp, want_bodies=False, want_markers=False, want_carry=False, out=res, **kw)
     e[1].record()
     qflat = res["qpos"].reshape(-1, nq)
     fko = eng.fk(qflat)
@@ -330,7 +330,7 @@ def main():
     def step():
         nonlocal out
         out = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                          root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False,
+                          root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, want_carry=False,
                           out=out)
 
     for _ in range(args.warmup):
@@ -455,7 +455,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             oc = eng.q_phase(kpc, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                             root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, out=oc)
+                             root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, want_carry=False, out=oc)
             e1.record()
             cev.append((e0, e1))
         torch.cuda.synchronize()
@@ -481,7 +481,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             lo = lm.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
-                            root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, out=lo)
+                            root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, want_carry=False, out=lo)
             e1.record()
             lev.append((e0, e1))
         torch.cuda.synchronize()

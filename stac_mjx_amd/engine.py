@@ -236,8 +236,9 @@ class Engine:
         return params, state, counters
 
     def q_phase(self, kp, *, part_masks, trunk_kps=None, root_kp_idx=-1, root_dims=7, do_root_opt=False, q_init=None,
-                want_bodies=True, want_markers=True, out=None):
-        """The q_phase of C clips x F frames (``stac_q_phase``).  kp: [C,F,3K]."""
+                want_bodies=True, want_markers=True, want_carry=True, out=None):
+        """The q_phase of C clips x F frames (``stac_q_phase``).  kp: [C,F,3K].  ``want_carry=False``: no ``carry_qpos`` (the pose
+        of every clip's last frame, [C,nq]: the warm start of a next pass) -- with one frame per clip it is ``qpos`` over again."""
         kp = self._dev(kp)
         if kp.dim() != 3 or kp.shape[2] != 3 * self.K:
             raise ValueError(f"kp must be [C, F, {3 * self.K}]")
@@ -252,7 +253,7 @@ class Engine:
             "qpos": o.get("qpos") if o.get("qpos") is not None else mk(Cn, F, self.nq),
             "frame_error": o.get("frame_error") if o.get("frame_error") is not None else mk(Cn, F),
             "counters": o.get("counters") if o.get("counters") is not None else torch.empty((Cn, F, 4), dtype=torch.int32, device=self.device),
-            "carry_qpos": o.get("carry_qpos") if o.get("carry_qpos") is not None else mk(Cn, self.nq),
+            "carry_qpos": (o.get("carry_qpos") if o.get("carry_qpos") is not None else mk(Cn, self.nq)) if want_carry else None,
             "xpos": (o.get("xpos") if o.get("xpos") is not None else mk(Cn, F, self.nbody, 3)) if want_bodies else None,
             "xquat": (o.get("xquat") if o.get("xquat") is not None else mk(Cn, F, self.nbody, 4)) if want_bodies else None,
             "marker_sites": (o.get("marker_sites") if o.get("marker_sites") is not None else mk(Cn, F, self.K, 3)) if want_markers else None,
