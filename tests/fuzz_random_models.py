@@ -1,6 +1,6 @@
 """Not collected by pytest: `python tests/fuzz_random_models.py N` runs tests/test_gpu_parity.py::test_random_models_bit_exact
 for N further seeds on a GPU box (random trees with free / ball / slide joints and oriented bodies, HIP == oracle bit for
-bit at 4 lanes, 16 lanes and in latency mode); combine with STAC_HIP_SPEC / STAC_HIP_SPECG / STAC_HIP_FLAGS to aim at one
+bit at 8 lanes, 16 lanes and in latency mode); combine with STAC_HIP_SPEC / STAC_HIP_SPECG / STAC_HIP_FLAGS to aim at one
 kernel shape.  Round 2: 2 300 models over the shapes, no mismatch."""
 import os, sys, traceback
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
@@ -8,19 +8,19 @@ import pytest
 import test_gpu_parity as T
 
 if os.environ.get("STAC_FUZZ_POISON"):
-    # fill the scratch memory of every wavefront slot with 0xFFFFFFFF before every launch (tests/tools/poison_scratch.hip): a
-    # spill slot that is reloaded before it is stored then poisons the FIRST launch instead of depending on the previous one
-    import ctypes, subprocess, torch
+    # fill the scratch memory and every vector register of every SIMD with a pattern before every launch
+    # (tests/tools/poison_scratch.hip): state that a launch reads before writing it then poisons the FIRST launch instead of
+    # depending on the previous one.  STAC_FUZZ_POISON=<hex pattern> (1 = 0xFFFFFFFF)
+    import ctypes, torch
+    from conftest import build_poison_tool
     from stac_mjx_amd import engine as _E
-    _so = os.path.join("build", "libpoison.so")
-    os.makedirs("build", exist_ok=True)
-    if not os.path.exists(_so):
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-shared", "-fPIC", "tests/tools/poison_scratch.hip", "-o", _so], check=True)
-    _P = ctypes.CDLL(os.path.abspath(_so))
+    _P = ctypes.CDLL(str(build_poison_tool()))
     _P.poison_scratch.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    _pat = os.environ["STAC_FUZZ_POISON"]
+    _pat = 0xFFFFFFFF if _pat == "1" else int(_pat, 16)
     _orig = _E.Engine.q_phase
     def _poisoned(self, *a, **k):
-        assert _P.poison_scratch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 0xFFFFFFFF) == 0
+        assert _P.poison_scratch(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), _pat) == 0
         return _orig(self, *a, **k)
     _E.Engine.q_phase = _poisoned
 bad = 0; ran = 0
