@@ -52,7 +52,7 @@ static int fail(int code, const std::string &msg) {
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
     int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1, stride_add = -1;
-    bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false, nodiet = false;
+    bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false, nodiet = false, nolean = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
         return v ? atoi(v) : -1;
@@ -60,7 +60,7 @@ struct DebugSwitches {
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
         handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR"); stride_add = geti("STAC_HIP_STRIDE_ADD");
-        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; nodiet = getenv("STAC_HIP_NODIET") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
+        noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; nolean = getenv("STAC_HIP_NOLEAN") != nullptr; nodiet = getenv("STAC_HIP_NODIET") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
 
@@ -829,6 +829,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
     const int nkinds = a.single ? 1 : a.P + 3;
     const DebugSwitches &dbg = m->dbg;
     if (dbg.flags >= 0) a.flags = dbg.flags;  // developer A/B switches (see stac_plan.hpp)
+    if (dbg.nolean) a.flags |= 8;  // (host only: the generic kernels even where a lean one fits)
     if (a.h.c_gg != a.h.c_sw || a.h.c_qe != a.h.c_sw) return fail(STAC_ERR_INVALID, "plan layout: the PG kernel expects c_qe == c_gg == c_sw");
 #ifdef STAC_PROFILE
     static unsigned long long *d_prof = nullptr;

@@ -55,9 +55,15 @@ namespace stac {
 // SPEC = number of evaluation roles per chain in latency mode (0 = throughput mode): 8 = four candidates + their four
 // momentum points; 4 = two + two (84 % of the iterations accept one of the first two candidates; the others take a
 // second trip with candidates 2 and 3): two chains per wavefront at 8 lanes per role, for large batches.
-template <int G, int NQR, int WPE, int SPEC>
+// SPECP = SPEC | 1: the LEAN kernels -- the same kernel with the launch-wide choices of the common case (phase mode, not a single
+// solve; a free root joint at qpos 0 .. 6; the uniform four-lanes-per-position FK program with 12-word records; every site in
+// registers; no developer flags) as compile-time constants inside the trip loop: the other paths drop out of the loop body
+// (10 % fewer instructions, no scalar spills).  The host takes it when all of that holds (launch_q_phase); same bits.
+template <int G, int NQR, int WPE, int SPECP>
 __global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a_in) {
+    constexpr int SPEC = SPECP & ~1;
+    constexpr bool LEAN = (SPECP & 1) != 0;
     const QArgs &a = a_in;
     static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 32 || G == 64)) || (SPEC == 4 && (G == 8 || G == 16)), "speculative mode: 8 (or 4) roles of G lanes");
     extern __shared__ float lds[];
@@ -360,8 +366,16 @@ void q_phase_kernel(const QArgs a_in) {
         KQArgs *ak_t = ak_base;
         if constexpr (kReloadPerTrip) asm volatile("" : "+s"(ak_t));
 #ifndef STAC_NO_PIN
-        const TripArgs a = trip_args<kVPin>(hot_a, *ak_t);
-        const TripHeader H = trip_header<kVPin>(hot_h, ak_t->h);
+        TripArgs a_t = trip_args<kVPin>(hot_a, *ak_t);
+        TripHeader H_t = trip_header<kVPin>(hot_h, ak_t->h);
+        if constexpr (LEAN) {  // (what the host has checked for this launch: launch_q_phase)
+            a_t.single = 0; a_t.flags = 0; a_t.free0p = 1;
+            H_t.fk_uniform = 1; H_t.fk_rec_words = 12;
+            __builtin_assume(4 * H_t.max_width <= G);
+            __builtin_assume(H_t.K <= kSiteRounds * G);
+        }
+        const TripArgs &a = a_t;
+        const TripHeader &H = H_t;
 #else
         KQArgs &a = *ak_t;
         const auto &H = a.h;
@@ -372,7 +386,7 @@ void q_phase_kernel(const QArgs a_in) {
         uint32_t *const MB = reinterpret_cast<uint32_t *>(lds + plan_words);
         const int nkinds = a.single ? 1 : a.P + 3;
         const int hstride = 3 * nqpad + 12;
-        const bool site_regs = K <= NSR * G;
+        const bool site_regs = LEAN || K <= NSR * G;
         const float *const jrec = P + H.off_joint, *const srec = P + H.off_site;
         const float *const lbv = P + H.off_lb, *const ubv = P + H.off_ub;
         const int *const quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
@@ -1106,7 +1120,9 @@ void q_phase_kernel(const QArgs a_in) {
             KQArgs *ak_c = ak_base;
             asm volatile("" : "+s"(ak_c));
 #ifndef STAC_NO_PIN
-            const TripArgs a = trip_args<kVPin>(hot_a, *ak_c);
+            TripArgs a_c = trip_args<kVPin>(hot_a, *ak_c);
+            if constexpr (LEAN) { a_c.single = 0; a_c.flags = 0; a_c.free0p = 1; }
+            const TripArgs &a = a_c;
             const TripHeader H = trip_header<kVPin>(hot_h, ak_c->h);
 #else
             KQArgs &a = *ak_c;
@@ -1502,8 +1518,9 @@ hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4,
     return hipGetLastError();
 }
 
-template <int G, int NQR, int WPE, int SPEC>
+template <int G, int NQR, int WPE, int SPECP>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
+    constexpr int SPEC = SPECP & ~1;  // (bit 0 = the lean kernel)
     constexpr int NR = SPEC ? SPEC : 1;
     constexpr int NW = SPEC ? (G * NR >= 64 ? G * NR / 64 : 1) : 1;  // SPEC: wavefronts per chain; more than one -> one chain per workgroup
     constexpr int CPW = SPEC ? (G * NR >= 64 ? 1 : 64 / (G * NR)) : 64 / G;  // chains per wavefront
@@ -1512,10 +1529,10 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
     // a resume launch has one slot per hand-off entry; with a chain queue the grid covers the resident slots only
     const int slots = a.resume ? a.resume_slots : (a.queue_slots > 0 ? std::min(a.queue_slots, a.C) : a.C);
     const int blocks = (slots + per_block - 1) / per_block;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE, SPEC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&q_phase_kernel<G, NQR, WPE, SPECP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((q_phase_kernel<G, NQR, WPE, SPEC>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
+    hipLaunchKernelGGL((q_phase_kernel<G, NQR, WPE, SPECP>), dim3(blocks), dim3(64 * wpb), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -1529,8 +1546,13 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 // (round 3: the wider ones, 300+ B of scratch, read spill slots before writing them); wider models take more lanes per role.
 #ifdef STAC_INST_SUBSET  // developer builds (experiments): only the shapes of the default bench and of its 250-frame-clip leg
 #define STAC_Q_SHAPES(X) X(16, 5, 2) X(16, 5, 3)
+#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 3)
+#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #define STAC_Q_SPEC_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #else
+// lean kernels (SPECP bit 0): the shapes that rodent-sized models run in -- large batches, the straggler hand-off, few long clips
+#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3)
+#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
     X(16, 5, 2) X(16, 5, 3) X(16, 8, 2) X(16, 8, 3) X(16, 16, 2)                 \
@@ -1556,7 +1578,17 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
                           int *capacity_out) {
     const int nq = a.h.nq;
     *capacity_out = 0;
+    // the lean kernels (q_phase_kernel, SPECP bit 0) where their compile-time choices are this launch's
+    const bool lean = !a.single && !a.bounds && a.flags == 0 && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
+                      4 * a.h.max_width <= G && a.h.K <= kSiteRounds * G;
     if (spec) {
+#define STAC_TRY_SPEC_LEAN(GG, RR, NRR)                             \
+    if (lean && G == GG && spec == NRR && nq <= GG * RR) {          \
+        *capacity_out = GG * RR;                                    \
+        return launch_q<GG, RR, 2, NRR | 1>(a, wpb, lds_bytes, s);  \
+    }
+        STAC_Q_SPEC_LEAN_SHAPES(STAC_TRY_SPEC_LEAN)
+#undef STAC_TRY_SPEC_LEAN
 #define STAC_TRY_SPEC(GG, RR, NRR)                                  \
     if (G == GG && spec == NRR && nq <= GG * RR) {                  \
         *capacity_out = GG * RR;                                    \
@@ -1567,6 +1599,13 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
         return hipErrorInvalidValue;
     }
     if (!q_phase_has_variant(G, nq, wpe)) wpe = 2;  // (every G has its 2-per-SIMD variants)
+#define STAC_TRY_LEAN(GG, RR, WW)                                   \
+    if (lean && G == GG && wpe == WW && nq <= GG * RR) {            \
+        *capacity_out = GG * RR;                                    \
+        return launch_q<GG, RR, WW, 1>(a, wpb, lds_bytes, s);       \
+    }
+    STAC_Q_LEAN_SHAPES(STAC_TRY_LEAN)
+#undef STAC_TRY_LEAN
 #define STAC_TRY(GG, RR, WW)                                        \
     if (G == GG && wpe == WW && nq <= GG * RR) {                    \
         *capacity_out = GG * RR;                                    \

@@ -1010,16 +1010,20 @@ def _mid_model(seed=5000, nbody=90, nq_expected=119):
 _SHAPE_CASES = [
     # (model, lanes, solver, environment)                                       instantiation
     ("rodent", 8, "pg", {}),                                                    # q<8,10,2,0>
-    ("rodent", 16, "pg", {"STAC_HIP_WPE": "2"}),                                # q<16,5,2,0>
-    ("rodent", 16, "pg", {"STAC_HIP_WPE": "3"}),                                # q<16,5,3,0>
+    ("rodent", 16, "pg", {"STAC_HIP_WPE": "2"}),                                # q<16,5,2,1>  (lean)
+    ("rodent", 16, "pg", {"STAC_HIP_WPE": "3"}),                                # q<16,5,3,1>
+    ("rodent", 16, "pg", {"STAC_HIP_WPE": "2", "STAC_HIP_NOLEAN": "1"}),        # q<16,5,2,0>  (generic)
+    ("rodent", 16, "pg", {"STAC_HIP_WPE": "3", "STAC_HIP_NOLEAN": "1"}),        # q<16,5,3,0>
     ("rodent", 32, "pg", {"STAC_HIP_WPE": "2"}),                                # q<32,3,2,0>
     ("rodent", 32, "pg", {"STAC_HIP_WPE": "4"}),                                # q<32,3,4,0>
     ("rodent", 64, "pg", {"STAC_HIP_WPE": "2"}),                                # q<64,2,2,0>
     ("rodent", 64, "pg", {"STAC_HIP_WPE": "4"}),                                # q<64,2,4,0>
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "8", "STAC_HIP_SPECR": "4"}),   # q<8,10,2,4>
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "8"}),         # q<8,10,2,8>
-    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),        # q<16,5,2,4>
-    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),        # q<32,3,2,8>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),        # q<16,5,2,5>  (lean)
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),        # q<32,3,2,9>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16", "STAC_HIP_NOLEAN": "1"}),   # q<16,5,2,4>  (generic)
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32", "STAC_HIP_NOLEAN": "1"}),   # q<32,3,2,8>
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "64"}),        # q<64,2,2,8>
     ("mid", 8, "pg", {}),                                                       # q<8,16,2,0>
     ("mid", 16, "pg", {"STAC_HIP_WPE": "2"}),                                   # q<16,8,2,0>

@@ -131,7 +131,8 @@ def test_no_shipped_instantiation_spills_beyond_the_gate(resource_rows):
            or r["sgpr_spill_count"] > MAX_SGPR_SPILLS]
     assert not bad, f"(kernel, scratch bytes, VGPR spills, SGPR spills) beyond the gate: {bad}"
     # the kernels the headline bench and its 250-frame-clip leg run: nothing in scratch at all
-    for name in ("q_phase_kernel<16, 5, 3, 0>", "q_phase_kernel<16, 5, 2, 4>", "q_phase_kernel<32, 3, 2, 8>"):
+    for name in ("q_phase_kernel<16, 5, 3, 1>", "q_phase_kernel<16, 5, 2, 5>", "q_phase_kernel<32, 3, 2, 9>",   # lean: what the bench runs
+                 "q_phase_kernel<16, 5, 3, 0>", "q_phase_kernel<16, 5, 2, 4>", "q_phase_kernel<32, 3, 2, 8>"):
         (r,) = [r for r in resource_rows if r["kernel"] == name]
         assert r["private_segment_fixed_size"] == 0 and r["sgpr_spill_count"] < 32, r
 
