@@ -136,9 +136,9 @@ __device__ __forceinline__ T pin_vector(T v) {
 #define STAC_PIN_ADDR V
 #endif
 #ifndef STAC_PIN_CTL
-#define STAC_PIN_CTL N
+#define STAC_PIN_CTL C
 #endif
-enum PinClass { PIN_N = 0, PIN_S = 1, PIN_V = 2 };
+enum PinClass { PIN_N = 0, PIN_S = 1, PIN_V = 2, PIN_C = 3 };
 #define STAC_PINCLASS_(c) PIN_##c
 #define STAC_PINCLASS(c) STAC_PINCLASS_(c)
 // (field, class): loop bounds, flags and sizes that feed scalar compares and branches; then LDS offsets
@@ -157,19 +157,20 @@ enum PinClass { PIN_N = 0, PIN_S = 1, PIN_V = 2 };
     X(single, STAC_PIN_CTL) X(P, STAC_PIN_CTL2) X(flags, STAC_PIN_CTL) X(free0p, STAC_PIN_CTL) X(root_fast, STAC_PIN_CTL)       \
     X(n_mlev_root, STAC_PIN_CTL2) X(n_run_root, STAC_PIN_CTL2) X(n_root_joints, STAC_PIN_CTL2) X(maxls, STAC_PIN_CTL)           \
     X(maxiter, STAC_PIN_CTL2) X(queue_slots, N) X(resume, N) X(root_trunk_lo, N) X(root_trunk_hi, N) X(tol, STAC_PIN_CTL2)
-template <bool VPIN, PinClass C, class T>
+// (VPIN: 1 = class V fields are pinned in vector registers; bit 1 set = class C fields are pinned in scalar registers)
+template <int VPIN, PinClass C, class T>
 __device__ __forceinline__ T pin_as(T v) {
-    if constexpr (C == PIN_S) return pin_scalar(v);
-    else if constexpr (C == PIN_V && VPIN) return pin_vector(v);
+    if constexpr (C == PIN_S || (C == PIN_C && (VPIN & 2))) return pin_scalar(v);
+    else if constexpr (C == PIN_V && (VPIN & 1)) return pin_vector(v);
     else return v;
 }
-template <bool VPIN, PinClass C>
-constexpr bool is_pinned() { return C == PIN_S || (C == PIN_V && VPIN); }
+template <int VPIN, PinClass C>
+constexpr bool is_pinned() { return C == PIN_S || (C == PIN_V && (VPIN & 1)) || (C == PIN_C && (VPIN & 2)); }
 struct HotHeader {  // PlanHeader fields of every trip (values)
     int32_t nq, K, nqpad, naj, nrange, max_width, off_joint, off_site, off_lb, off_ub, off_range, off_fkstep, off_fkroot, fk_hdr_words,
         n_mlev_hdr, n_mlev, fk_rec_words, fk_uniform, c_bx, c_ja, c_jn, c_sw, c_sink, c_rw, c_qe, c_qsv, chain_stride;
 };
-template <bool VPIN, class KH>
+template <int VPIN, class KH>
 __device__ __forceinline__ HotHeader pin_header(const KH &h) {  // before the loop: the pinned ones
     HotHeader o = {};
 #define STAC_PIN(f, c) if constexpr (is_pinned<VPIN, STAC_PINCLASS(c)>()) o.f = pin_as<VPIN, STAC_PINCLASS(c)>(h.f);
@@ -181,7 +182,7 @@ struct TripHeader : HotHeader {  // + the other PlanHeader fields (references in
     KRef<int32_t> nbody, njnt, nab, nlev, nquat, has_ball, off_lev_adr, off_body, off_qpos0, off_quat_adr, off_active, total_words,
         plan_skip, core_words, c_gg, c_kp, c_r2, stride_regs, stride_lds, stride_forced, nst, nqj, kpow2;
 };
-template <bool VPIN, class KH>
+template <int VPIN, class KH>
 __device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH &k) {  // inside the loop: pinned values + fresh reads
     HotHeader t = hot;
 #define STAC_PIN(f, c) if constexpr (!is_pinned<VPIN, STAC_PINCLASS(c)>()) t.f = k.f;
@@ -197,7 +198,7 @@ struct HotArgs {  // QArgs fields of every trip (values)
     uint32_t root_trunk_lo, root_trunk_hi;
     float tol;
 };
-template <bool VPIN, class KA>
+template <int VPIN, class KA>
 __device__ __forceinline__ HotArgs pin_args(const KA &a) {
     HotArgs o = {};
 #define STAC_PIN(f, c) if constexpr (is_pinned<VPIN, STAC_PINCLASS(c)>()) o.f = pin_as<VPIN, STAC_PINCLASS(c)>(a.f);
@@ -215,7 +216,7 @@ struct TripArgs : HotArgs {
     KRef<uint32_t *> counters_out;
     KRef<float *> q_carry_out;
 };
-template <bool VPIN, class KA>
+template <int VPIN, class KA>
 __device__ __forceinline__ TripArgs trip_args(const HotArgs &hot, const KA &k) {
     HotArgs t = hot;
 #define STAC_PIN(f, c) if constexpr (!is_pinned<VPIN, STAC_PINCLASS(c)>()) t.f = k.f;

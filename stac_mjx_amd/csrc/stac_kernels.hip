@@ -354,8 +354,11 @@ void q_phase_kernel(const QArgs a_in) {
 #ifndef STAC_VPIN
 #define STAC_VPIN (SPEC != 0 && G >= 16)
 #endif
+#ifndef STAC_SPIN
+#define STAC_SPIN false
+#endif
 #ifndef STAC_NO_PIN
-    constexpr bool kVPin = STAC_VPIN;
+    constexpr int kVPin = (STAC_VPIN ? 1 : 0) | (STAC_SPIN ? 2 : 0);
     const HotHeader hot_h = pin_header<kVPin>(a.h);
     const HotArgs hot_a = pin_args<kVPin>(a);
 #endif
@@ -1551,7 +1554,7 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 #define STAC_Q_SPEC_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #else
 // lean kernels (SPECP bit 0): the shapes that rodent-sized models run in -- large batches, the straggler hand-off, few long clips
-#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3)
+#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2)
 #define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
