@@ -304,7 +304,8 @@ __device__ __forceinline__ void st_tvec2(float *p, V3 v) { st_tpos(p + kXq, v); 
 // slide: the displacement).  This keeps the sincos off the serial chain of the FK that follows.  The result sits in
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
 // naj_lim: the leading joints to do (all, or -- root fast trips -- only the joints of the root passes' coordinates).
-template <class HT>
+// HINGES: every joint of the loop is a hinge (lean kernels: a uniform program below a free root that is handled apart) -- no dispatch.
+template <bool HINGES = false, class HT>
 __device__ __forceinline__ void joint_local_prepass(const HT &H, const float *P, float *CBc, const int lf, const int gf,
                                                     const int naj_lim, const int j_first = 0) {
     const float *jrec = P + H.off_joint;
@@ -313,7 +314,7 @@ __device__ __forceinline__ void joint_local_prepass(const HT &H, const float *P,
         const float *jr = jrec + 12 * j;
         const int4 ji = lds4i(jr);  // type, qadr, slo, shi
         const int ty = ji.x, ad = ji.y;
-        if (ty == JHINGE) {
+        if (HINGES || ty == JHINGE) {
             const float4 jp4 = lds4(jr + 4);  // pos, q0
             const float4 ja4 = lds4(jr + 8);  // axis, slot
             const float angle = qe[ad] - jp4.w;

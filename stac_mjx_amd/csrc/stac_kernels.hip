@@ -561,7 +561,12 @@ void q_phase_kernel(const QArgs a_in) {
             const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
             const float v = (1.0f - mi) * q0[r] + mi * pt;
             if (r == 0) v0 = v;
-            if (e < nq && !(a.free0p && e < 7)) qe[e] = v;
+            if constexpr (LEAN) {  // (a select on the address instead of a branch round the store: coordinates nobody stages go to the sink)
+                float *dst = (e < nq && !(e < 7)) ? qe + e : CB + H.c_sink;
+                *dst = v;
+            } else {
+                if (e < nq && !(a.free0p && e < 7)) qe[e] = v;
+            }
         }
         if (a.free0p) free0_prepass(v0, a.free0p - 1);
         }
@@ -569,7 +574,7 @@ void q_phase_kernel(const QArgs a_in) {
         PROF_TICK(1);  // stage
 
         if (!(lite && a.free0p)) {  // (a root fast trip on a free root has nothing else to prepare)
-            joint_local_prepass(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0);
+            joint_local_prepass<LEAN>(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0);
             wave_sync();
         }
         PROF_TICK(10);  // joint-local pre-pass
@@ -729,6 +734,9 @@ void q_phase_kernel(const QArgs a_in) {
             CBx[H.c_rw + kXf * r + co] = acc;
         };
         // (B) one joint: its range's wrench, then the joint formulas; crefx = the root position the moments refer to
+        // (lean kernels: the joints this is called for -- all but the free root, which has its own path -- are hinges: the host has
+        //  checked that the model has no ball joint and that its FK program is uniform, launch_q_phase)
+        constexpr bool LEAN_HINGES = LEAN && SPEC == 0;  // (the latency kernels pass the free root through here as well)
         auto joint_gradient = [&](const int j, float *CBx, const V3 crefx, float *ggx) {
             const float *jax_ = CBx + H.c_ja, *qsvx = CBx + H.c_qsv, *jnx = CBx + H.c_jn;
             const float *jr = jrec + 12 * j;
@@ -740,7 +748,7 @@ void q_phase_kernel(const QArgs a_in) {
                 const V3 anchor = ld_tpos(jax_ + kXf * j);
                 const Q4 prequat = ld_tquat(jax_ + kXf * j);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
-                if (ty == JHINGE) {
+                if (LEAN_HINGES || ty == JHINGE) {
                     ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
                 } else if (ty == JSLIDE) {
                     ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), Fs);
@@ -831,7 +839,12 @@ void q_phase_kernel(const QArgs a_in) {
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
-                if (e < nq && ((abits >> r) & 1u)) gnew[r] = gg[e];
+                if constexpr (LEAN) {  // (read, then select: no branch per register; gg has nqpad + 7 words)
+                    const float gv = gg[e < nq ? e : 0];
+                    gnew[r] = (e < nq && ((abits >> r) & 1u)) ? gv : gnew[r];
+                } else {
+                    if (e < nq && ((abits >> r) & 1u)) gnew[r] = gg[e];
+                }
             }
             if (a.free0p) {  // the free root joint: one component per lane, its four divisions side by side
                 const float gv = free0_gradient(CB, cref, __builtin_bit_cast(int, jrec[11]), a.free0p - 1);
@@ -1582,8 +1595,9 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     const int nq = a.h.nq;
     *capacity_out = 0;
     // the lean kernels (q_phase_kernel, SPECP bit 0) where their compile-time choices are this launch's
+    // (nqj == 1 and a uniform program: the free root is the only quaternion joint and no joint is a slide: all others are hinges)
     const bool lean = !a.single && !a.bounds && a.flags == 0 && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
-                      4 * a.h.max_width <= G && a.h.K <= kSiteRounds * G;
+                      4 * a.h.max_width <= G && a.h.K <= kSiteRounds * G && a.h.nqj == 1 && !a.h.has_ball;
     if (spec) {
 #define STAC_TRY_SPEC_LEAN(GG, RR, NRR)                             \
     if (lean && G == GG && spec == NRR && nq <= GG * RR) {          \
