@@ -515,7 +515,21 @@ void q_phase_kernel(const QArgs a_in) {
             const float qw = __shfl(v, gb + 3, 64), qx = __shfl(v, gb + 4, 64), qy = __shfl(v, gb + 5, 64), qz = __shfl(v, gb + 6, 64);
             const float n = __builtin_sqrtf(FMA(qz, qz, FMA(qy, qy, FMA(qx, qx, qw * qw))));
             const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
-            if (lg < 3) {
+            if constexpr (LEAN) {
+                // the same stores without a branch: every lane divides, the lanes that hold nothing aim at the sink entry
+                const float qn = v / dn;
+                const int c = lg - 3;  // 0 .. 3 = w, x, y, z on lanes 3 .. 6
+                const float val = lg < 3 ? v : qn;
+                float *const sink = CB + H.c_sink;
+                float *d_qe = lg < 7 ? qe + lg : sink;
+                float *d_ja = lg < 3 ? ja + lg : (lg < 7 ? ja + kXq + (c == 0 ? 3 : c - 1) : sink + 1);
+                float *d_qs = (lg >= 3 && lg < 7) ? qsv + 4 * qord + c : sink + 2;
+                float *d_jn = lg == 3 ? jn + qord : sink + 3;
+                *d_qe = val;
+                *d_ja = val;
+                *d_qs = qn;
+                *d_jn = n;
+            } else if (lg < 3) {
                 qe[lg] = v;
                 ja[lg] = v;
             } else if (lg < 7) {
@@ -748,20 +762,22 @@ void q_phase_kernel(const QArgs a_in) {
                 const V3 anchor = ld_tpos(jax_ + kXf * j);
                 const Q4 prequat = ld_tquat(jax_ + kXf * j);
                 const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
-                if (LEAN_HINGES || ty == JHINGE) {
+                // (lean kernels know the types: joint 0 is the free root, every other one a hinge)
+                const bool is_hinge = LEAN_HINGES ? true : (LEAN ? j != 0 : ty == JHINGE);
+                if (is_hinge) {
                     ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
-                } else if (ty == JSLIDE) {
+                } else if (!LEAN && ty == JSLIDE) {
                     ggx[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), Fs);
                 } else {
                     int qa = ad;
                     V3 tl = tau;
-                    if (ty == JFREE) {
+                    if (LEAN || ty == JFREE) {
                         st3(ggx + ad, Fs);
                         qa = ad + 3;
                     } else {
                         tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});
                     }
-                    const int qord = __builtin_bit_cast(int, lds4(jr + 4).w);  // ordinal among the quaternion joints
+                    const int qord = LEAN ? 0 : __builtin_bit_cast(int, lds4(jr + 4).w);  // ordinal among the quaternion joints
                     const Q4 qh = ld4(qsvx + 4 * qord);  // saved by the pre-pass
                     const V3 u = {qh.x, qh.y, qh.z};
                     const V3 uxt = cross3(u, tl);
