@@ -960,6 +960,12 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         const int root_fast = a.root_fast;
         if ((a.flags & 2) || G < root_fast) a.root_fast = 0;  // root fast trips need the FK program and the root coordinates in register 0
         a.free0p = free0_ordinal_p1(m, G);
+        {   // flags bit 4: every active joint but the free root (which lanes 0 .. 6 handle apart) is a hinge: the joint loops of the
+            // generic kernels then run the hinge formulas without looking at the joint type (mouse, fly; the lean kernels know it)
+            bool hinges = a.free0p == 1;
+            for (int j = 1; j < m->h.naj && hinges; ++j) hinges = m->h_aj_type[j] == STAC_JNT_HINGE;
+            a.flags = (a.flags & ~16) | (hinges ? 16 : 0);
+        }
         const int32_t *perm_in = a.perm;
         int32_t *place_in = a.place;
         {

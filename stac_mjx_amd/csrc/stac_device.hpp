@@ -305,11 +305,25 @@ __device__ __forceinline__ void st_tvec2(float *p, V3 v) { st_tpos(p + kXq, v); 
 // the ja slot that the joint's pre-joint quaternion takes once FK has consumed it, so it needs no LDS of its own.
 // naj_lim: the leading joints to do (all, or -- root fast trips -- only the joints of the root passes' coordinates).
 // HINGES: every joint of the loop is a hinge (lean kernels: a uniform program below a free root that is handled apart) -- no dispatch.
+// hinges_rt: the same, known at launch time (QArgs::flags bit 4: generic kernels on models whose joints are all hinges below the root).
 template <bool HINGES = false, class HT>
 __device__ __forceinline__ void joint_local_prepass(const HT &H, const float *P, float *CBc, const int lf, const int gf,
-                                                    const int naj_lim, const int j_first = 0) {
+                                                    const int naj_lim, const int j_first = 0, const bool hinges_rt = false) {
     const float *jrec = P + H.off_joint;
     float *qe = CBc + H.c_qe, *jn = CBc + H.c_jn, *ja = CBc + H.c_ja, *qsv = CBc + H.c_qsv;
+    if (!HINGES && hinges_rt) {  // (wave-uniform) one straight loop, no dispatch
+        for (int j = lf + j_first; j < naj_lim; j += gf) {
+            const float *jr = jrec + 12 * j;
+            const int ad = reinterpret_cast<const int *>(jr)[1];
+            const float4 jp4 = lds4(jr + 4);  // pos, q0
+            const float4 ja4 = lds4(jr + 8);  // axis, slot
+            const float angle = qe[ad] - jp4.w;
+            float sn, cs;
+            sincos_(angle * 0.5f, &sn, &cs);
+            st_tquat(ja + kXf * j, Q4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn});
+        }
+        return;
+    }
     for (int j = lf + j_first; j < naj_lim; j += gf) {
         const float *jr = jrec + 12 * j;
         const int4 ji = lds4i(jr);  // type, qadr, slo, shi

@@ -588,7 +588,7 @@ void q_phase_kernel(const QArgs a_in) {
         PROF_TICK(1);  // stage
 
         if (!(lite && a.free0p)) {  // (a root fast trip on a free root has nothing else to prepare)
-            joint_local_prepass<LEAN>(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0);
+            joint_local_prepass<LEAN>(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0, (a.flags & 16) != 0 && j0 == 1);
             wave_sync();
         }
         PROF_TICK(10);  // joint-local pre-pass
@@ -849,7 +849,22 @@ void q_phase_kernel(const QArgs a_in) {
             }
             PROF_TICK(5);  // range sums
             const int naj_g = n_ml_root > 0 ? a.n_root_joints : H.naj;  // pruned root-pass trip: only the root's joints
-            for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
+            if (!LEAN && (a.flags & 16) && j0 == 1) {
+                // (launch-wide: every joint but the free root is a hinge -- QArgs::flags bit 4: the hinge formula without the dispatch)
+                for (int j = lg + 1; j < naj_g; j += G) {
+                    const float *jr = jrec + 12 * j;
+                    const int ad = reinterpret_cast<const int *>(jr)[1];
+                    const float4 ja4 = lds4(jr + 8);  // axis, range id
+                    const float *rw = CB + H.c_rw + kXf * __builtin_bit_cast(int, ja4.w);
+                    const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
+                    const V3 anchor = ld_tpos(ja + kXf * j);
+                    const Q4 prequat = ld_tquat(ja + kXf * j);
+                    const V3 tau = sub3(T0, cross3(sub3(anchor, cref), Fs));
+                    gg[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
+                }
+            } else {
+                for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
+            }
             wave_sync();
             const uint32_t abits = SPEC ? mbits : (MB[nkinds * G + lg] & mbits);  // optimised coordinates that HAVE a gradient entry
 #pragma unroll
@@ -1612,7 +1627,7 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     *capacity_out = 0;
     // the lean kernels (q_phase_kernel, SPECP bit 0) where their compile-time choices are this launch's
     // (nqj == 1 and a uniform program: the free root is the only quaternion joint and no joint is a slide: all others are hinges)
-    const bool lean = !a.single && !a.bounds && a.flags == 0 && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
+    const bool lean = !a.single && !a.bounds && (a.flags & ~16) == 0 && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
                       4 * a.h.max_width <= G && a.h.K <= kSiteRounds * G && a.h.nqj == 1 && !a.h.has_ball;
     if (spec) {
 #define STAC_TRY_SPEC_LEAN(GG, RR, NRR)                             \

@@ -224,7 +224,7 @@ struct QArgs {
     int32_t resume_slots;   // grid size of the resume launch (= capacity)
     int32_t queue_slots;    // > 0: chain queue -- the grid covers this many chain slots (the resident ones); a group that
                             // finishes a chain takes the next unstarted one (ctl[4]) instead of leaving its slot idle
-    int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program; bit 2 (host only): a uniform FK program runs through the per-step dispatch; bit 3 (host only): no lean kernel (A/B switches)
+    int32_t flags;          // bit 0: do NOT fuse the x_next gradient into accepted line-search evaluations; bit 1: level-loop FK instead of the FK program; bit 2 (host only): a uniform FK program runs through the per-step dispatch; bit 3 (host only): no lean kernel (A/B switches); bit 4 (set by the host per launch): every active joint but the free root is a hinge
     float tol;
     int32_t maxiter, maxls;
     // outputs
