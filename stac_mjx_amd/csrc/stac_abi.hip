@@ -79,6 +79,8 @@ struct stac_model {
     int32_t *d_jnt_type = nullptr, *d_jnt_qposadr = nullptr;
     float *d_jnt_pos = nullptr, *d_jnt_axis = nullptr, *d_qpos0 = nullptr;
     int32_t *d_site_bodyid = nullptr;
+    int32_t *d_fk_brec = nullptr, *d_fk_jrec = nullptr, *d_fk_sites = nullptr;  // packed tables of fk_kernel (build_fk_tables)
+    int fk_nslots = 0;
     float *d_site_pos = nullptr;  // [K,3] offsets for the stand-alone FK / m-phase kernels (mirrors the plan's SiteRec.pos)
     uint32_t *d_order = nullptr;  // chain order / placement work space: [3K floats rest sites][4096 buckets][kPlaceWords][C key bits][C perm]
     size_t order_chains = 0;
@@ -112,9 +114,76 @@ struct stac_model {
         M.jnt_pos = d_jnt_pos; M.jnt_axis = d_jnt_axis; M.qpos0 = d_qpos0;
         M.site_bodyid = d_site_bodyid;
         M.site_pos = d_site_pos;
+        M.fk_brec = d_fk_brec; M.fk_jrec = d_fk_jrec; M.fk_sites = d_fk_sites; M.fk_nslots = fk_nslots;
         return M;
     }
 };
+
+// The packed tables of fk_kernel (stac_kernels.hip; layout: FullModel in stac_plan.hpp).  A lane carries the transform of the
+// body it has just computed in registers; a body whose children do not ALL follow it directly parks its transform in an LDS slot
+// until its last child has read it.  Slots are handed out like registers: a slot is free again from the step of its owner's
+// last child on (that step reads before it writes).
+struct FkTables {
+    std::vector<int32_t> brec, jrec, sites;
+    int nslots = 0;
+};
+static FkTables build_fk_tables(const stac_model_tables *t) {
+    const int nb = t->nbody, nj = t->njnt, K = t->nsite;
+    FkTables ft;
+    ft.brec.assign((size_t)16 * std::max(nb, 1), 0);
+    ft.jrec.assign((size_t)12 * std::max(nj, 1), 0);
+    auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    std::vector<int> last_child(nb, -1), slot_of(nb, -1), owner;  // owner[slot] = body parked there
+    std::vector<char> far_child(nb, 0);
+    for (int b = 1; b < nb; ++b) {
+        const int p = t->body_parentid[b];
+        last_child[p] = b;
+        if (p != b - 1) far_child[p] = 1;
+    }
+    for (int b = 0; b < nb; ++b) {
+        int32_t *r = &ft.brec[(size_t)16 * b];
+        const int p = b ? t->body_parentid[b] : -1;
+        r[0] = (b && p != b - 1) ? slot_of[p] : -1;
+        r[1] = -1;
+        if (far_child[b]) {
+            int sl = -1;
+            for (int k = 0; k < (int)owner.size() && sl < 0; ++k)
+                if (last_child[owner[k]] <= b) sl = k;
+            if (sl < 0) { sl = (int)owner.size(); owner.push_back(b); }
+            owner[sl] = b;
+            slot_of[b] = sl;
+            r[1] = sl;
+        }
+        r[2] = t->body_jntadr[b] < 0 ? 0 : t->body_jntadr[b];
+        r[3] = t->body_jntnum[b];
+        for (int c = 0; c < 3; ++c) r[4 + c] = f2i(t->body_pos[3 * b + c]);
+        for (int c = 0; c < 4; ++c) r[8 + c] = f2i(t->body_quat[4 * b + c]);
+        r[7] = (int32_t)ft.sites.size();
+        for (int k = 0; k < K; ++k)
+            if (t->site_bodyid[k] == b) ft.sites.push_back(k);
+        r[12] = (int32_t)ft.sites.size();
+    }
+    ft.nslots = (int)owner.size();
+    for (int j = 0; j < nj; ++j) {
+        int32_t *r = &ft.jrec[(size_t)12 * j];
+        r[0] = t->jnt_type[j];
+        r[1] = t->jnt_qposadr[j];
+        r[2] = f2i(t->qpos0[t->jnt_qposadr[j]]);
+        r[3] = t->jnt_qposadr[j];
+        for (int c = 0; c < 3; ++c) { r[4 + c] = f2i(t->jnt_pos[3 * j + c]); r[8 + c] = f2i(t->jnt_axis[3 * j + c]); }
+    }
+    // the kernel requests the first coordinate of the joint it will visit TWO steps on while it works on the current one: the order
+    // of the visits is the bodies' (body 0 has none); brec[13], brec[14] of body 0 = the coordinates of the first two joints visited
+    std::vector<int> visit;
+    for (int b = 1; b < nb; ++b)
+        for (int j = t->body_jntadr[b]; j < t->body_jntadr[b] + t->body_jntnum[b]; ++j) visit.push_back(j);
+    for (size_t i = 0; i < visit.size(); ++i) {
+        if (i < 2) ft.brec[13 + i] = t->jnt_qposadr[visit[i]];
+        if (i + 2 < visit.size()) ft.jrec[(size_t)12 * visit[i] + 3] = t->jnt_qposadr[visit[i + 2]];
+    }
+    if (ft.sites.empty()) ft.sites.push_back(0);
+    return ft;
+}
 
 template <typename T>
 static hipError_t upload(T **dst, const T *src, size_t n) {
@@ -703,6 +772,13 @@ extern "C" stac_model *stac_model_create(const stac_model_tables *t) {
     chk(upload(&m->d_qpos0, t->qpos0, (size_t)nq));
     chk(upload(&m->d_site_bodyid, t->site_bodyid, (size_t)K));
     chk(upload(&m->d_site_pos, t->site_pos, (size_t)K * 3));
+    {
+        const FkTables ft = build_fk_tables(t);
+        m->fk_nslots = ft.nslots;
+        chk(upload(&m->d_fk_brec, ft.brec.data(), ft.brec.size()));
+        chk(upload(&m->d_fk_jrec, ft.jrec.data(), ft.jrec.size()));
+        chk(upload(&m->d_fk_sites, ft.sites.data(), ft.sites.size()));
+    }
     m->masks_bytes = (size_t)kMaxKinds * m->h.nqpad + 4 * (size_t)K + 64;
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_masks), m->masks_bytes));
     chk(hipMalloc(reinterpret_cast<void **>(&m->d_bounds), 2 * (size_t)m->h.nqpad * sizeof(float)));
@@ -727,7 +803,7 @@ extern "C" void stac_model_destroy(stac_model *m) {
     DeviceGuard dg(m);
     void *ptrs[] = {m->d_bounds, m->d_blob, m->d_body_parentid, m->d_body_jntadr, m->d_body_jntnum, m->d_body_pos,
                     m->d_body_quat, m->d_jnt_type, m->d_jnt_qposadr, m->d_jnt_pos, m->d_jnt_axis,
-                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_masks, m->d_scratch, m->d_lm_tab, m->d_ctl, m->d_hand, m->d_order};
+                    m->d_qpos0, m->d_site_bodyid, m->d_site_pos, m->d_fk_brec, m->d_fk_jrec, m->d_fk_sites, m->d_masks, m->d_scratch, m->d_lm_tab, m->d_ctl, m->d_hand, m->d_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete m;

@@ -1296,132 +1296,132 @@ void q_phase_kernel(const QArgs a_in) {
 // ------------------------------------------------------------------------------------------------
 // stand-alone forward kinematics: one lane per pose, whole body tree (utils.kinematics)
 // ------------------------------------------------------------------------------------------------
-// The outputs are the bulk of what Stac.ik_only produces (rodent: 2 448 of 2 728 B per frame), so they leave the chip as
-// full cache lines: a workgroup keeps the body transforms of its pb poses in LDS -- one row per pose, odd row strides, so
-// that the lanes' private rows sit in different banks and a child's read of its parent never leaves the CU (it used to be a
-// global round trip through the output array) -- and all 64 lanes then copy the rows out, consecutive lanes to consecutive
-// words of the pose-major arrays.  The marker sites are computed in that copy phase, one (pose, site) per lane.  Same
-// operations per pose as before: bit-identical to the oracle.
+// A lane walks the bodies of ITS pose in index order (parents before children) and keeps the current body's transform in
+// registers: a child that follows its parent directly -- the chains that make up most of every tree (the rodent's tail: 26
+// bodies) -- reads nothing.  A body with a child further down the list parks its transform in one of a few LDS slots (7 words per
+// lane, lane-private columns: no bank conflicts, no synchronisation; the host allots the slots like registers, FkTables in
+// stac_abi.hip: rodent 3, mouse 4), so a wavefront needs 0.9 KB of LDS per slot and a CU holds as many wavefronts as its SIMDs
+// take.  The model tables are packed records (16 words per body, 12 per joint) read through the SCALAR cache: every lane of a
+// wavefront is at the same body, so body offsets, joint axes and site offsets arrive in SGPRs and cost no vector memory
+// traffic at all.  The coordinate of the NEXT joint is requested before the current body's results are stored (VMEM counts
+// loads and stores in one in-order counter on gfx9: a load issued after a store waits for that store's acknowledgement).
+// Body transforms leave through an LDS staging row per lane (kFkChunk bodies: 56 words, odd stride): every kFkChunk bodies the
+// wavefront turns the rows round -- half a wavefront per pose, consecutive lanes to consecutive words of the pose-major arrays --
+// so a store instruction touches 2 x 128 B instead of 64 lines (measured: strided 12 / 16 B stores run at 60 G transactions/s,
+// whatever their size: 268 us per 100 000 rodent poses on stores alone).  Same operations per pose as the oracle, in the same
+// order: bit-identical.
 // normalize = 0: quaternions in qpos are used as they are (the q_phase kernel has already applied
 // kinematics' write-back normalisation; MJX's xquat IS that stored quaternion).
-// The model tables (5 KB for the rodent) are staged in LDS as well: read from global memory body by body they put a
-// 1 us round trip on every step of a lane's serial walk down the tree.
-struct FkLds { int parent, jadr, jnum, bpos, bquat, jtype, jqadr, jpos, jaxis, q0, rows_p, rows_q, rows_c, total; };
-__host__ __device__ inline FkLds fk_lds_layout(int nbody, int njnt, int nq, int pb) {
-    FkLds L;
-    int o = 0;
-    L.parent = o; o += nbody;
-    L.jadr = o; o += nbody;
-    L.jnum = o; o += nbody;
-    L.bpos = o; o += 3 * nbody;
-    L.bquat = o; o += 4 * nbody;
-    L.jtype = o; o += njnt;
-    L.jqadr = o; o += njnt;
-    L.jpos = o; o += 3 * njnt;
-    L.jaxis = o; o += 3 * njnt;
-    L.q0 = o; o += nq;
-    L.rows_p = o; o += pb * ((3 * nbody) | 1);
-    L.rows_q = o; o += pb * ((4 * nbody) | 1);
-    L.rows_c = o; o += pb * (nq | 1);  // the poses' coordinates (normalised in place)
-    L.total = o;
-    return L;
-}
-// pb = poses per workgroup of 64 lanes (<= 64; the host sizes it so that several workgroups fit a CU's LDS)
+typedef const __attribute__((address_space(4))) int32_t *KInt;
+typedef const __attribute__((address_space(4))) float *KFlt;
+constexpr int kFkChunk = 8, kFkStride = 7 * kFkChunk + 1;  // bodies per staged chunk; words per lane's staging row (odd)
 __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, int N, float *qpos_norm_out,
-                                                 float *xpos, float *xquat, float *site_xpos, int normalize, int pb) {
+                                                 float *__restrict__ xpos, float *__restrict__ xquat,
+                                                 float *__restrict__ site_xpos, int normalize) {
     extern __shared__ float lds[];
     const int t = threadIdx.x;
-    const int n0 = blockIdx.x * pb, nb = min(pb, N - n0);
-    const int WP = 3 * M.nbody, WQ = 4 * M.nbody, SP = WP | 1, SQ = WQ | 1;
-    const FkLds L = fk_lds_layout(M.nbody, M.njnt, M.nq, pb);
-    int *li = reinterpret_cast<int *>(lds);
-    for (int i = t; i < M.nbody; i += 64) { li[L.parent + i] = M.body_parentid[i]; li[L.jadr + i] = M.body_jntadr[i]; li[L.jnum + i] = M.body_jntnum[i]; }
-    for (int i = t; i < 3 * M.nbody; i += 64) lds[L.bpos + i] = M.body_pos[i];
-    for (int i = t; i < 4 * M.nbody; i += 64) lds[L.bquat + i] = M.body_quat[i];
-    for (int i = t; i < M.njnt; i += 64) { li[L.jtype + i] = M.jnt_type[i]; li[L.jqadr + i] = M.jnt_qposadr[i]; }
-    for (int i = t; i < 3 * M.njnt; i += 64) { lds[L.jpos + i] = M.jnt_pos[i]; lds[L.jaxis + i] = M.jnt_axis[i]; }
-    for (int i = t; i < M.nq; i += 64) lds[L.q0 + i] = M.qpos0[i];
-    float *rows_p = lds + L.rows_p, *rows_q = lds + L.rows_q, *rows_c = lds + L.rows_c;
-    const int SC = M.nq | 1;
-    {   // the block's coordinates: consecutive lanes read consecutive words of the pose-major input
-        const float *in = qpos + (size_t)n0 * M.nq;
-        int row = t / M.nq, col = t % M.nq;
-        for (int w = t; w < nb * M.nq; w += 64) {
-            rows_c[row * SC + col] = in[w];
-            col += 64;
-            while (col >= M.nq) { col -= M.nq; ++row; }
+    const int n0 = blockIdx.x * 64, n = n0 + t;
+    const bool live = n < N;  // (the lanes past the end walk the last pose again: they help with the copies, their own results go nowhere)
+    const int nc = live ? n : N - 1;
+    const float *q = qpos + (size_t)nc * M.nq;
+    float *qn = qpos_norm_out && live ? qpos_norm_out + (size_t)n * M.nq : nullptr;
+    float *sx = site_xpos && live ? site_xpos + (size_t)n * 3 * M.K : nullptr;
+    float *xp_blk = xpos ? xpos + (size_t)n0 * 3 * M.nbody : nullptr;
+    float *xq_blk = xquat ? xquat + (size_t)n0 * 4 * M.nbody : nullptr;
+    float *stage = lds + max(M.fk_nslots, 1) * (7 * 64);
+    float *mine = stage + t * kFkStride;
+    const int nvalid = min(64, N - n0);
+    if (qpos_norm_out) {
+        // the normalised copy of the coordinates: the wavefront's 64 rows are one contiguous block, copied as such (full lines);
+        // the quaternion joints then overwrite their four words below (same wavefront, same address: in order).
+        const float *src = qpos + (size_t)n0 * M.nq;
+        float *dst = qpos_norm_out + (size_t)n0 * M.nq;
+        if (dst != src) {  // (in place there is nothing to copy; partially overlapping arrays are not an input)
+            const float *__restrict__ sr = src;
+            float *__restrict__ dr = dst;
+#pragma unroll 8
+            for (int i = t, tot = nvalid * M.nq; i < tot; i += 64) dr[i] = sr[i];
         }
     }
-    __syncthreads();
-    if (t < nb) {
-        float *q = rows_c + t * SC;  // (free / ball quaternions are normalised in place: what kinematics writes back)
-        float *xp = rows_p + t * SP, *xq = rows_q + t * SQ;
-        float *const qn = q;
-        xp[0] = xp[1] = xp[2] = 0.f;
-        xq[0] = 1.f; xq[1] = xq[2] = xq[3] = 0.f;
-        for (int b = 1; b < M.nbody; ++b) {
-            const int p = li[L.parent + b];
-            const Q4 pquat = ld4(xq + 4 * p);
-            V3 pos = add3(ld3(xp + 3 * p), rotate(ld3(lds + L.bpos + 3 * b), pquat));
-            Q4 quat = qmul(pquat, ld4(lds + L.bquat + 4 * b));
-            const int j0 = li[L.jadr + b], j1 = j0 + li[L.jnum + b];
+    KInt brec = (KInt)M.fk_brec, jrec = (KInt)M.fk_jrec, sites = (KInt)M.fk_sites;
+    KFlt spos = (KFlt)M.site_pos;  // (constant for the duration of a launch: stac_set_site_pos is stream-ordered)
+    float *slot = lds + t;
+    V3 pos = {0.f, 0.f, 0.f};
+    Q4 quat = {1.f, 0.f, 0.f, 0.f};
+    float qnext = q[brec[13]], qnext2 = q[brec[14]];  // the first two joints visited (0 in a model without joints: any readable word)
+    for (int b = 0; b < M.nbody; ++b) {
+        KInt br = brec + 16 * b;
+        KFlt bf = (KFlt)br;
+        if (b > 0) {
+            const int psrc = br[0];
+            if (psrc >= 0) {  // the parent is not the body before this one: its parked transform
+                const float *sp = slot + psrc * (7 * 64);
+                pos = {sp[0], sp[64], sp[128]};
+                quat = {sp[192], sp[256], sp[320], sp[384]};
+            }
+            const Q4 pquat = quat;
+            pos = add3(pos, rotate(V3{bf[4], bf[5], bf[6]}, pquat));
+            quat = qmul(pquat, Q4{bf[8], bf[9], bf[10], bf[11]});
+            const int j0 = br[2], j1 = j0 + br[3];
             for (int j = j0; j < j1; ++j) {
-                const int ty = li[L.jtype + j], ad = li[L.jqadr + j];
-                const V3 jp = ld3(lds + L.jpos + 3 * j), jax = ld3(lds + L.jaxis + 3 * j);
+                KInt jr = jrec + 12 * j;
+                KFlt jf = (KFlt)jr;
+                const int ty = jr[0], ad = jr[1];
+                const float qv = qnext, q0 = jf[2];
+                qnext = qnext2;
+                qnext2 = q[jr[3]];  // first coordinate of the joint two visits on (the last ones: their own again)
+                const V3 jp = {jf[4], jf[5], jf[6]}, jax = {jf[8], jf[9], jf[10]};
                 if (ty == JFREE) {
-                    pos = ld3(q + ad);
+                    pos = {qv, q[ad + 1], q[ad + 2]};
                     float nn;
                     quat = normalize ? normalize4(ld4(q + ad + 3), &nn) : ld4(q + ad + 3);
-                    st4(qn + ad + 3, quat);
+                    if (qn) st4(qn + ad + 3, quat);
                 } else if (ty == JHINGE) {
                     const V3 anchor = add3(rotate(jp, quat), pos);
                     float sn, cs;
-                    sincos_((q[ad] - lds[L.q0 + ad]) * 0.5f, &sn, &cs);
+                    sincos_((qv - q0) * 0.5f, &sn, &cs);
                     quat = qmul(quat, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
                     pos = sub3(anchor, rotate(jp, quat));
                 } else if (ty == JSLIDE) {
                     const V3 axis = rotate(jax, quat);
-                    const float d = q[ad] - lds[L.q0 + ad];
+                    const float d = qv - q0;
                     pos = {FMA(axis.x, d, pos.x), FMA(axis.y, d, pos.y), FMA(axis.z, d, pos.z)};
                 } else {
                     const V3 anchor = add3(rotate(jp, quat), pos);
                     float nn;
-                    const Q4 qloc = normalize ? normalize4(ld4(q + ad), &nn) : ld4(q + ad);
-                    st4(qn + ad, qloc);
+                    const Q4 raw = {qv, q[ad + 1], q[ad + 2], q[ad + 3]};
+                    const Q4 qloc = normalize ? normalize4(raw, &nn) : raw;
+                    if (qn) st4(qn + ad, qloc);
                     quat = qmul(quat, qloc);
                     pos = sub3(anchor, rotate(jp, quat));
                 }
             }
-            st3(xp + 3 * b, pos);
-            st4(xq + 4 * b, quat);
         }
-    }
-    __syncthreads();
-    // copy phase: word w of the block's pose-major output <- row (w / W), column (w % W); the lanes walk (row, column) with
-    // additions only
-    auto copy_rows = [&](float *dst, const float *rows, const int W, const int S) {
-        if (!dst) return;
-        float *out = dst + (size_t)n0 * W;
-        int row = t / W, col = t % W;
-        for (int w = t; w < nb * W; w += 64) {
-            out[w] = rows[row * S + col];
-            col += 64;
-            while (col >= W) { col -= W; ++row; }
+        const int save = br[1];
+        if (save >= 0) {
+            float *sp = slot + save * (7 * 64);
+            sp[0] = pos.x; sp[64] = pos.y; sp[128] = pos.z;
+            sp[192] = quat.w; sp[256] = quat.x; sp[320] = quat.y; sp[384] = quat.z;
         }
-    };
-    copy_rows(xpos, rows_p, WP, SP);
-    copy_rows(xquat, rows_q, WQ, SQ);
-    copy_rows(qpos_norm_out, rows_c, M.nq, SC);
-    if (site_xpos) {
-        const int K = M.K;
-        int row = t / K, k = t % K;
-        for (int e = t; e < nb * K; e += 64) {
-            const int b = M.site_bodyid[k];
-            st3(site_xpos + ((size_t)n0 * K + e) * 3,
-                add3(ld3(rows_p + row * SP + 3 * b), rotate(ld3(M.site_pos + 3 * k), ld4(rows_q + row * SQ + 4 * b))));
-            k += 64;
-            while (k >= K) { k -= K; ++row; }
+        const int cb = b & (kFkChunk - 1);
+        st4(mine + 4 * cb, quat);
+        st3(mine + 4 * kFkChunk + 3 * cb, pos);
+        if (cb == kFkChunk - 1 || b == M.nbody - 1) {  // turn the staged chunk round: lanes = (pose parity, word)
+            const int b0 = b - cb, h = t >> 5, w = t & 31;
+            wave_sync();
+            if (xq_blk && w < 4 * (cb + 1))
+#pragma unroll 4
+                for (int p = h; p < nvalid; p += 2) xq_blk[(size_t)p * 4 * M.nbody + 4 * b0 + w] = stage[p * kFkStride + w];
+            if (xp_blk && w < 3 * (cb + 1))
+#pragma unroll 4
+                for (int p = h; p < nvalid; p += 2) xp_blk[(size_t)p * 3 * M.nbody + 3 * b0 + w] = stage[p * kFkStride + 4 * kFkChunk + w];
+            wave_sync();
         }
+        if (sx)
+            for (int s = br[7], s1 = br[12]; s < s1; ++s) {  // the marker sites of this body
+                const int k = sites[s];
+                st3(sx + 3 * k, add3(pos, rotate(V3{spos[3 * k], spos[3 * k + 1], spos[3 * k + 2]}, quat)));
+            }
     }
 }
 
@@ -1667,15 +1667,11 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
 hipError_t launch_fk(const FullModel &M, const float *qpos, int N, float *qn, float *xpos, float *xquat,
                      float *site_xpos, int normalize, hipStream_t s) {
     if (N <= 0) return hipSuccess;
-    // poses per workgroup: a power of two whose rows fit a fifth of a CU's LDS next to the tables (rodent: 16, five workgroups
-    // per CU; the mouse's 6.3 KB per pose: 4) -- the lanes' serial walks need all the wavefronts a CU can hold
-    int pb = 64;
-    while (pb > 1 && (size_t)fk_lds_layout(M.nbody, M.njnt, M.nq, pb).total * sizeof(float) > 32 * 1024) pb >>= 1;
-    const size_t lds_bytes = (size_t)fk_lds_layout(M.nbody, M.njnt, M.nq, pb).total * sizeof(float);
-    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;  // (a single pose of more than 5 000 bodies)
+    const size_t lds_bytes = ((size_t)std::max(M.fk_nslots, 1) * 7 + kFkStride) * 64 * sizeof(float);  // (rodent: 5.4 + 14.6 KB per wavefront)
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;  // (a tree with more than 83 open branch points)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fk_kernel, dim3((N + pb - 1) / pb), dim3(64), lds_bytes, s, M, qpos, N, qn, xpos, xquat, site_xpos, normalize, pb);
+    hipLaunchKernelGGL(fk_kernel, dim3((N + 63) / 64), dim3(64), lds_bytes, s, M, qpos, N, qn, xpos, xquat, site_xpos, normalize);
     return hipGetLastError();
 }
 
