@@ -65,6 +65,38 @@ def test_fk_random_poses_non_unit_quaternions(rodent_setup):
         np.testing.assert_array_equal(_np(out["qpos"][f]), r["qpos"])
 
 
+@pytest.mark.parametrize("model", ["fly", "mouse", "random_ball_slide", "random_fixed_root"])
+def test_fk_output_subsets_ragged_blocks(model, fly_setup, mouse_setup):
+    """fk_kernel has one path per set of requested outputs (marker sites after the walk when both body arrays are wanted,
+    during it otherwise; the normalised coordinates as a block copy + the quaternion joints' words) and works in blocks of 64
+    poses: every subset, on 150 poses (two full blocks and a ragged one) and on a single pose, equals the oracle bit for bit."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    if model in ("fly", "mouse"):
+        fs = fly_setup if model == "fly" else mouse_setup
+        t, lb, ub = fs.tables, fs.lb, fs.ub
+    else:
+        rng = np.random.default_rng(77 if model == "random_ball_slide" else 78)
+        t = _random_tables(rng, 37, model == "random_ball_slide", p_slide=0.2, p_ball=0.2 if model == "random_ball_slide" else 0.0)
+        lb, ub = np.full(t.nq, -np.inf, np.float32), np.full(t.nq, np.inf, np.float32)
+    eng, orc = Engine(t, lb, ub), Oracle(t)
+    rng = np.random.default_rng(11)
+    q = (np.asarray(t.qpos0, np.float32)[None] + rng.normal(0, 0.4, (150, t.nq))).astype(np.float32)
+    ref = [orc.fk(x.copy()) for x in q]
+    names = ("qpos", "xpos", "xquat", "site_xpos")
+    for want in [names, names[1:], ("site_xpos",), ("xpos", "xquat"), ("xquat", "site_xpos"), ("qpos",)]:
+        for n in (150, 1):
+            out = eng.fk(q[:n], want=want)
+            for k in names:
+                if k in want:
+                    got = _np(out[k]).reshape(n, -1)
+                    exp = np.stack([np.asarray(r[k], np.float32).reshape(-1) for r in ref[:n]])
+                    np.testing.assert_array_equal(got, exp, err_msg=f"{model} {want} N={n} {k}")
+                else:
+                    assert out[k] is None
+
+
 # ---- single solves (the StacCore.q_opt seam) ------------------------------------------------------------
 @pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
 @pytest.mark.parametrize("which", ["all", "part", "root_trunk"])
