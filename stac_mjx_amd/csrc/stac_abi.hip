@@ -849,6 +849,14 @@ static int fk_impl(const stac_model *mc, const float *qpos, int32_t N, float *qn
     return STAC_OK;
 }
 
+// Diagnostics, not part of include/stac_hip.h: {G, NQR, WPE, SPECP} of the most recent q_phase_kernel launch of the calling thread
+// (SPECP bit 0 = a lean kernel, SPECP & ~1 = evaluation roles of the latency mode; tests/test_gpu_parity.py checks that the shapes
+// the bench runs in are the lean ones).
+namespace stac { extern thread_local int g_last_q_shape[4]; }
+extern "C" void stac_debug_last_q_kernel(int32_t *out4) {
+    for (int i = 0; i < 4; ++i) out4[i] = stac::g_last_q_shape[i];
+}
+
 extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, float *qn, float *xpos,
                            float *xquat, float *site_xpos, void *stream) {
     return fk_impl(m, qpos, N, qn, xpos, xquat, site_xpos, 1, stream);
@@ -892,6 +900,15 @@ static int pick_lanes(const stac_model *m, int requested, int nchains, int nkind
 // joint: ordinal 0, JointRec::q0 in build_plan) and its seven coordinates in register 0 of lanes 0 .. 6
 static int free0_ordinal_p1(const stac_model *m, int G) {
     return (G >= 8 && m->h.naj > 0 && m->h_aj_type[0] == STAC_JNT_FREE && m->h_aj_qadr[0] == 0 && !m->dbg.nofree0) ? 1 : 0;
+}
+
+// QArgs::flags bit 4 for a launch whose free0p is set: every active joint but the free root (which lanes 0 .. 6 handle apart) is a
+// hinge -- the joint loops of the generic kernels then run the hinge formulas without looking at the joint type (mouse, fly), and
+// the lean kernels, which have it compiled in, may be chosen (launch_q_phase)
+static void set_hinges_flag(const stac_model *m, QArgs &a) {
+    bool hinges = a.free0p == 1;
+    for (int j = 1; j < m->h.naj && hinges; ++j) hinges = m->h_aj_type[j] == STAC_JNT_HINGE;
+    a.flags = (a.flags & ~16) | (hinges ? 16 : 0);
 }
 
 static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nchains, hipStream_t s) {
@@ -958,6 +975,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
             a.free0p = free0_ordinal_p1(m, sg);
+            set_hinges_flag(m, a);
             a.perm = nullptr; a.place = nullptr;  // (latency mode: few chains, nothing to balance)
             e = launch_q_phase(a, sg, sh.waves_per_block, 2, sr, lds, s, &cap);
             a.ctl = nullptr; a.queue_slots = 0;
@@ -1036,12 +1054,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         const int root_fast = a.root_fast;
         if ((a.flags & 2) || G < root_fast) a.root_fast = 0;  // root fast trips need the FK program and the root coordinates in register 0
         a.free0p = free0_ordinal_p1(m, G);
-        {   // flags bit 4: every active joint but the free root (which lanes 0 .. 6 handle apart) is a hinge: the joint loops of the
-            // generic kernels then run the hinge formulas without looking at the joint type (mouse, fly; the lean kernels know it)
-            bool hinges = a.free0p == 1;
-            for (int j = 1; j < m->h.naj && hinges; ++j) hinges = m->h_aj_type[j] == STAC_JNT_HINGE;
-            a.flags = (a.flags & ~16) | (hinges ? 16 : 0);
-        }
+        set_hinges_flag(m, a);
         const int32_t *perm_in = a.perm;
         int32_t *place_in = a.place;
         {
@@ -1079,6 +1092,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             b.h.chain_stride = q_chain_stride(m->h, kLatG);
             int cap2 = 0;
             b.free0p = free0_ordinal_p1(m, kLatG);
+            set_hinges_flag(m, b);
             e = launch_q_phase(b, kLatG, ss.waves_per_block, 2, kLatR, spec_lds_bytes(m->h, kLatG, nkinds, ss.chains_per_block, kLatR), s, &cap2);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
             if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.waves_per_block);

@@ -1565,9 +1565,14 @@ hipError_t launch_ctl_init(int32_t *ctl, int v0, int v1, int v2, int v3, int v4,
     return hipGetLastError();
 }
 
+// the instantiation of the most recent q_phase launch of this thread (tests: which kernel did the host choose?  stac_abi.hip,
+// stac_debug_last_q_kernel)
+thread_local int g_last_q_shape[4] = {0, 0, 0, 0};
+
 template <int G, int NQR, int WPE, int SPECP>
 static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_t s) {
     constexpr int SPEC = SPECP & ~1;  // (bit 0 = the lean kernel)
+    g_last_q_shape[0] = G; g_last_q_shape[1] = NQR; g_last_q_shape[2] = WPE; g_last_q_shape[3] = SPECP;
     constexpr int NR = SPEC ? SPEC : 1;
     constexpr int NW = SPEC ? (G * NR >= 64 ? G * NR / 64 : 1) : 1;  // SPEC: wavefronts per chain; more than one -> one chain per workgroup
     constexpr int CPW = SPEC ? (G * NR >= 64 ? 1 : 64 / (G * NR)) : 64 / G;  // chains per wavefront
@@ -1627,7 +1632,7 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     *capacity_out = 0;
     // the lean kernels (q_phase_kernel, SPECP bit 0) where their compile-time choices are this launch's
     // (nqj == 1 and a uniform program: the free root is the only quaternion joint and no joint is a slide: all others are hinges)
-    const bool lean = !a.single && !a.bounds && (a.flags & ~16) == 0 && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
+    const bool lean = !a.single && !a.bounds && a.flags == 16 /* only hinges below the root (set_hinges_flag), no developer flag */ && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
                       4 * a.h.max_width <= G && a.h.K <= kSiteRounds * G && a.h.nqj == 1 && !a.h.has_ball;
     if (spec) {
 #define STAC_TRY_SPEC_LEAN(GG, RR, NRR)                             \

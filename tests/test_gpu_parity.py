@@ -1074,6 +1074,37 @@ _SHAPE_CASES = [
 ]
 
 
+def _last_q_kernel(eng):
+    import ctypes
+
+    out = (ctypes.c_int32 * 4)()
+    eng.lib.stac_debug_last_q_kernel(out)
+    return tuple(out)
+
+
+def test_default_launches_of_the_rodent_take_the_lean_kernels(rodent_setup, rodent_mocap, monkeypatch):
+    """The shapes the bench and `ik_only` run the rodent in exist as lean kernels (SPECP bit 0); the host must pick them on its
+    own at every one of its three launch sites -- throughput launch, latency launch, hand-off resume -- and must not when
+    STAC_HIP_NOLEAN asks for the generic ones (a launch site that forgets the hinge flag falls back silently: -13 %)."""
+    from stac_mjx_amd.engine import Engine
+
+    fs = rodent_setup
+    kw = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=True)
+    eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=6)
+    eng.q_phase(np.tile(rodent_mocap[300:306], (1000, 1)).reshape(6000, 1, 69), **kw)  # chain queue + hand-off: the resume launch is last
+    assert _last_q_kernel(eng) == (16, 5, 2, 5)
+    eng.q_phase(rodent_mocap[300:312].reshape(4, 3, 69), **kw)  # few chains: latency mode, four wavefronts per chain
+    assert _last_q_kernel(eng) == (32, 3, 2, 9)
+    eng16 = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=6, lanes_per_chain=16)
+    eng16.q_phase(rodent_mocap[300:310].reshape(10, 1, 69), **kw)  # throughput kernel on request, no hand-off at this size
+    g, nqr, wpe, specp = _last_q_kernel(eng16)
+    assert (g, nqr, specp) == (16, 5, 1) and wpe in (2, 3)
+    monkeypatch.setenv("STAC_HIP_NOLEAN", "1")
+    gen = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=6)
+    gen.q_phase(rodent_mocap[300:312].reshape(4, 3, 69), **kw)
+    assert _last_q_kernel(gen) == (32, 3, 2, 8)
+
+
 @pytest.mark.parametrize("model,lanes,solver,env", _SHAPE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else
                          "-".join(f"{k[9:]}{x}" for k, x in v.items()) or "auto")
 def test_every_shipped_instantiation_twice(rodent_setup, mouse_setup, rodent_mocap, monkeypatch, model, lanes, solver, env):
