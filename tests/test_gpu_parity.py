@@ -97,6 +97,24 @@ def test_fk_output_subsets_ragged_blocks(model, fly_setup, mouse_setup):
                     assert out[k] is None
 
 
+def test_fk_normalised_coordinates_in_place(rodent_setup):
+    """`stac_fk` with qpos_norm_out == qpos (the caller normalises its own array): same result as into a separate array."""
+    import torch
+    from stac_mjx_amd.engine import _ptr
+
+    fs = rodent_setup
+    eng = _engine(fs)
+    rng = np.random.default_rng(3)
+    q = (fs.tables.qpos0[None] + rng.normal(0, 0.4, (130, 74))).astype(np.float32)
+    ref = eng.fk(q)
+    qd = torch.from_numpy(q).to(eng.device)
+    xpos = torch.empty((130, eng.nbody, 3), dtype=torch.float32, device=eng.device)
+    eng._check(eng.lib.stac_fk(eng._h, _ptr(qd), 130, _ptr(qd), _ptr(xpos), None, None, eng._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(qd, ref["qpos"]) and torch.equal(xpos, ref["xpos"])
+    assert not np.array_equal(_np(qd), q)  # (the free joint's quaternion was not a unit one)
+
+
 # ---- single solves (the StacCore.q_opt seam) ------------------------------------------------------------
 @pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
 @pytest.mark.parametrize("which", ["all", "part", "root_trunk"])
