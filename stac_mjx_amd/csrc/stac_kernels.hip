@@ -1300,16 +1300,18 @@ void q_phase_kernel(const QArgs a_in) {
 // registers: a child that follows its parent directly -- the chains that make up most of every tree (the rodent's tail: 26
 // bodies) -- reads nothing.  A body with a child further down the list parks its transform in one of a few LDS slots (7 words per
 // lane, lane-private columns: no bank conflicts, no synchronisation; the host allots the slots like registers, FkTables in
-// stac_abi.hip: rodent 3, mouse 4), so a wavefront needs 0.9 KB of LDS per slot and a CU holds as many wavefronts as its SIMDs
-// take.  The model tables are packed records (16 words per body, 12 per joint) read through the SCALAR cache: every lane of a
-// wavefront is at the same body, so body offsets, joint axes and site offsets arrive in SGPRs and cost no vector memory
-// traffic at all.  The coordinate of the NEXT joint is requested before the current body's results are stored (VMEM counts
-// loads and stores in one in-order counter on gfx9: a load issued after a store waits for that store's acknowledgement).
-// Body transforms leave through an LDS staging row per lane (kFkChunk bodies: 56 words, odd stride): every kFkChunk bodies the
-// wavefront turns the rows round -- half a wavefront per pose, consecutive lanes to consecutive words of the pose-major arrays --
-// so a store instruction touches 2 x 128 B instead of 64 lines (measured: strided 12 / 16 B stores run at 60 G transactions/s,
-// whatever their size: 268 us per 100 000 rodent poses on stores alone).  Same operations per pose as the oracle, in the same
-// order: bit-identical.
+// stac_abi.hip: rodent 3, mouse 4: 1.8 KB per slot and wavefront).  The model tables are packed records (16 words per body, 12
+// per joint) read through the SCALAR cache: every lane of a wavefront is at the same body, so body offsets, joint axes and site
+// offsets arrive in SGPRs and cost no vector memory traffic at all.  The coordinate of the joint two visits AHEAD is requested
+// before the current body's results are stored (VMEM counts loads and stores in one in-order counter on gfx9: a load issued
+// after a store waits for that store's acknowledgement).
+// Body transforms leave through an LDS staging row per lane (kFkChunk bodies: 56 words, odd stride; 14.6 KB per wavefront, which
+// with the slots makes eight wavefronts per CU): every kFkChunk bodies the wavefront turns the rows round -- half a wavefront per
+// pose, consecutive lanes to consecutive words of the pose-major arrays -- so a store instruction touches 2 x 128 B instead of
+// 64 lines (measured: scattered or partial-line stores run at 60 G transactions/s chip-wide whatever their size: 268 us per
+// 100 000 rodent poses with every transform stored straight from the registers, 137 us like this).  The marker sites still go
+// out one by one (12 B each; staging them as well would halve the resident wavefronts).  Same operations per pose as the oracle,
+// in the same order: bit-identical.
 // normalize = 0: quaternions in qpos are used as they are (the q_phase kernel has already applied
 // kinematics' write-back normalisation; MJX's xquat IS that stored quaternion).
 typedef const __attribute__((address_space(4))) int32_t *KInt;

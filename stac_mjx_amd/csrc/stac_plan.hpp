@@ -176,8 +176,9 @@ struct FullModel {
     const int32_t *site_bodyid;
     const float *site_pos;  // points INTO the plan blob (single source of truth for the offsets)
     // packed tables of fk_kernel (stac_abi.hip, build_fk_tables): per body 16 words {parent slot or -1 = the body before, slot to
-    // park in or -1, jntadr, jntnum | pos xyz, first site | quat wxyz | end of sites, (body 0: qposadr of the first joint visited, of the second), 0}; per joint 12 words {type, qposadr,
-    // qpos0[qposadr], qposadr of the joint visited two steps on | pos xyz, 0 | axis xyz, 0}; the site ids sorted by body
+    // park in or -1, jntadr, jntnum | pos xyz, first site | quat wxyz | end of sites, (body 0 only: qposadr of the first joint
+    // visited, of the second), 0}; per joint 12 words {type, qposadr, qpos0[qposadr], qposadr of the joint visited two steps on |
+    // pos xyz, 0 | axis xyz, 0}; the site ids sorted by body
     const int32_t *fk_brec, *fk_jrec, *fk_sites;
     int32_t fk_nslots;
 };
