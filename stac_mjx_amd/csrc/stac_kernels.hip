@@ -569,9 +569,12 @@ void q_phase_kernel(const QArgs a_in) {
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + lg;
             const float cr = clipf(FMA(-eta_s, g[r], y[r]), lbs[r], ubs[r]);
-            float pt;
-            if (SPEC && st_in == ST_SPEC) pt = role < NC ? cr : FMA(spec_beta, cr - x[r], cr);
-            else pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cr : x[r]);
+            float pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cr : x[r]);
+            if constexpr (SPEC != 0) {  // (selects, not branches: every lane computes the momentum point, the roles it is for take it)
+                const float mom = FMA(spec_beta, cr - x[r], cr);
+                const float ps = role < NC ? cr : mom;
+                pt = st_in == ST_SPEC ? ps : pt;
+            }
             const float mi = ((mbits >> r) & 1u) ? 1.0f : 0.0f;
             const float v = (1.0f - mi) * q0[r] + mi * pt;
             if (r == 0) v0 = v;
