@@ -466,13 +466,15 @@ void q_phase_kernel(const QArgs a_in) {
         // needs (the oracle's separate VG_X evaluation runs the very same FK).  The step size doubles
         // after every iteration, so the first candidate is almost always rejected and the second
         // accepted: evaluate the gradient together with every candidate after the first.
-        const bool ls_wants_grad = (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
+        // (the latency kernels never enter ST_LS / ST_VG_X -- a solve goes VG_Y, then SPEC trips to its end --: what belongs to
+        //  those states is compiled out of them here and in the transition below)
+        const bool ls_wants_grad = SPEC == 0 && (st_in == ST_LS) && (nls >= 1) && !(a.flags & 1);
         const bool want_grad = (st_in == ST_VG_Y) || (st_in == ST_VG_X) || ls_wants_grad || (SPEC && st_in == ST_SPEC);
         const bool any_grad = __any(want_grad);
         // The gradient pass is issued for the whole wavefront as soon as one group needs it, so a FIRST candidate gets
         // its gradient for free whenever a neighbour chain asks for one -- and if it is accepted (one iteration in six)
         // the separate evaluation of x_next disappears as well.
-        const bool ls_with_grad = (st_in == ST_LS) && !(a.flags & 1) && (nls >= 1 || any_grad);
+        const bool ls_with_grad = SPEC == 0 && (st_in == ST_LS) && !(a.flags & 1) && (nls >= 1 || any_grad);
         // t_next and the momentum coefficient of the running iteration (functions of t only; recomputed every
         // trip instead of being carried); SPEC: this group's candidate scale 2^-c
         const float spec_pow = SPEC ? ((role % NC) == 0 ? 1.0f : (role % NC) == 1 ? 0.5f : (role % NC) == 2 ? 0.25f : 0.125f) : 1.0f;
@@ -569,7 +571,7 @@ void q_phase_kernel(const QArgs a_in) {
         for (int r = 0; r < NQR; ++r) {
             const int e = r * G + lg;
             const float cr = clipf(FMA(-eta_s, g[r], y[r]), lbs[r], ubs[r]);
-            float pt = (st_in == ST_VG_Y) ? y[r] : ((st_in == ST_LS) ? cr : x[r]);
+            float pt = (st_in == ST_VG_Y) ? y[r] : ((SPEC == 0 && st_in == ST_LS) ? cr : x[r]);
             if constexpr (SPEC != 0) {  // (selects, not branches: every lane computes the momentum point, the roles it is for take it)
                 const float mom = FMA(spec_beta, cr - x[r], cr);
                 const float ps = role < NC ? cr : mom;
@@ -981,7 +983,7 @@ void q_phase_kernel(const QArgs a_in) {
         }
         {
             const float eta_s = (SPEC && st_in == ST_SPEC) ? eta * spec_pow : eta;
-            const bool isx = st_in == ST_VG_X, isl = st_in == ST_LS || (SPEC && st_in == ST_SPEC);
+            const bool isx = SPEC == 0 && st_in == ST_VG_X, isl = SPEC ? st_in == ST_SPEC : st_in == ST_LS;
             float t0[NQR], t1[NQR];
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -998,7 +1000,7 @@ void q_phase_kernel(const QArgs a_in) {
         }
         PROF_TICK(7);  // transition terms + nq sums
         bool fused = false;  // accepted a candidate whose gradient is already in gnew
-        if (st_in == ST_LS) {
+        if (SPEC == 0 && st_in == ST_LS) {
             c_ls++;
             const float lhs = eta * (loss - fy);
             const float rhs = eta * sum1 + 0.5f * sum0 + eps;
@@ -1025,7 +1027,7 @@ void q_phase_kernel(const QArgs a_in) {
         }
         // stopping residual of x_next: either this trip evaluated x (VG_X) or the accepted candidate
         // came with its gradient (fused)
-        if (__any(fused)) {
+        if (SPEC == 0 && __any(fused)) {
             float t0[NQR];
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
@@ -1036,7 +1038,7 @@ void q_phase_kernel(const QArgs a_in) {
             const float e2 = group_tree_sum<G, NQR>(t0);
             if (fused) sum0 = e2;
         }
-        if (st_in == ST_VG_X || fused) {
+        if (SPEC == 0 && (st_in == ST_VG_X || fused)) {
             fx = loss;
             error = __builtin_sqrtf(sum0);
             stepsize = (eta <= 1e-6f) ? 1.0f : eta / 0.5f;  // eta still holds the accepted step
