@@ -132,7 +132,7 @@ void q_phase_kernel(const QArgs a_in) {
     float *qe = sw, *kpl = CB + H.c_kp;
     // Sites k = r * G + lg, r < kSiteRounds, belong to this lane: their keypoints and loss terms stay in registers when
     // that covers all K sites (the host then lays the chain out without the c_kp / c_r2 regions); else through LDS.
-    constexpr int NSR = kSiteRounds;
+    constexpr int NSR = LEAN ? lean_site_rounds(G) : kSiteRounds;
     const bool site_regs = K <= NSR * G;
     float kpr[NSR][3];
 #pragma unroll
@@ -375,7 +375,7 @@ void q_phase_kernel(const QArgs a_in) {
             a_t.single = 0; a_t.flags = 0; a_t.free0p = 1;
             H_t.fk_uniform = 1; H_t.fk_rec_words = 12;
             __builtin_assume(4 * H_t.max_width <= G);
-            __builtin_assume(H_t.K <= kSiteRounds * G);
+            __builtin_assume(H_t.K <= NSR * G);
         }
         const TripArgs &a = a_t;
         const TripHeader &H = H_t;
@@ -645,9 +645,9 @@ void q_phase_kernel(const QArgs a_in) {
                 // (the others' terms are exact zeros, and nobody reads their wrench entries: see the range sum below)
                 float v = 0.0f;
                 if (trunk_r >= 0) {
-                    const float kx = trunk_r == 0 ? kpr[0][0] : (trunk_r == 1 ? kpr[1][0] : kpr[NSR - 1][0]);
-                    const float ky = trunk_r == 0 ? kpr[0][1] : (trunk_r == 1 ? kpr[1][1] : kpr[NSR - 1][1]);
-                    const float kz = trunk_r == 0 ? kpr[0][2] : (trunk_r == 1 ? kpr[1][2] : kpr[NSR - 1][2]);
+                    const float kx = trunk_r == 0 ? kpr[0][0] : (trunk_r == 1 ? kpr[NSR > 1 ? 1 : 0][0] : kpr[NSR - 1][0]);
+                    const float ky = trunk_r == 0 ? kpr[0][1] : (trunk_r == 1 ? kpr[NSR > 1 ? 1 : 0][1] : kpr[NSR - 1][1]);
+                    const float kz = trunk_r == 0 ? kpr[0][2] : (trunk_r == 1 ? kpr[NSR > 1 ? 1 : 0][2] : kpr[NSR - 1][2]);
                     v = site_term(trunk_r * G + lg, kx, ky, kz, true);
                 }
 #pragma unroll
@@ -1640,7 +1640,7 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
     // the lean kernels (q_phase_kernel, SPECP bit 0) where their compile-time choices are this launch's
     // (nqj == 1 and a uniform program: the free root is the only quaternion joint and no joint is a slide: all others are hinges)
     const bool lean = !a.single && !a.bounds && a.flags == 16 /* only hinges below the root (set_hinges_flag), no developer flag */ && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
-                      4 * a.h.max_width <= G && a.h.K <= kSiteRounds * G && a.h.nqj == 1 && !a.h.has_ball;
+                      4 * a.h.max_width <= G && a.h.K <= lean_site_rounds(G) * G && a.h.nqj == 1 && !a.h.has_ball;
     if (spec) {
 #define STAC_TRY_SPEC_LEAN(GG, RR, NRR)                             \
     if (lean && G == GG && spec == NRR && nq <= GG * RR) {          \
