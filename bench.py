@@ -45,6 +45,24 @@ def load_setup(model="rodent"):
     return fs, cfg
 
 
+def job_shape(scaling: str, frames: int, frames_per_clip: int, rank: int, world: int) -> dict:
+    """Which clips a rank of the job solves.  weak: every rank brings `frames` frames (the default bench: per-GPU work fixed);
+    strong: `frames` frames in the WHOLE job (BASELINE configs[3]: 1 M frames at 250 per clip = 4 000 clips over the ranks).
+    Clips go to ranks in contiguous blocks (dist.shard_range, what Stac.ik_only does: stac_mjx/stac.py:405-440).
+    `value` of a line = frames_total x steps / max-over-ranks time (job_value)."""
+    from stac_mjx_amd.dist import shard_range
+
+    F = int(frames_per_clip)
+    c_total = frames // F if scaling == "strong" else world * (frames // F)
+    lo, hi = shard_range(c_total, rank, world)
+    return {"scaling": scaling, "F": F, "clips_total": c_total, "lo": lo, "hi": hi, "clips_rank": hi - lo,
+            "frames_rank": (hi - lo) * F, "frames_total": c_total * F}
+
+
+def job_value(shape: dict, steps: int, elapsed_max_over_ranks: float) -> float:
+    return shape["frames_total"] * steps / elapsed_max_over_ranks
+
+
 def cpu_baseline(fs, cfg, kp_host, target_s=15.0):
     """The oracle (CPU restatement, kind='port') on a bounded sample of the same workload."""
     from oracle import Oracle
@@ -163,8 +181,16 @@ def run_run_mode(args, rank, local_rank, world, dist):
     offsets = synth_offsets(fs)
     eng.set_site_pos(offsets)
     fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
-    kp_host, _ = synth_keypoints(fs, fk, C, F, seed=1000 * rank + 11, noise_seed=1000 * rank + 12)
-    kp_flat = kp_host.reshape(C * F, -1)
+    # ONE global dataset of world x C clips, the same on every rank: `Stac.ik_only` shards the clips itself
+    # (dist.shard_range), so every rank solves C of them -- weak scaling: `--frames` frames per GPU
+    from stac_mjx_amd import dist as sdist
+
+    shape = job_shape("weak", C * F, F, rank, world)
+    kp_glob, _ = synth_keypoints(fs, fk, shape["clips_total"], F, seed=11, noise_seed=12)
+    kp_flat = kp_glob.reshape(shape["frames_total"], -1)
+    lo, hi = shape["lo"], shape["hi"]
+    assert (lo, hi) == sdist.shard_range(shape["clips_total"])  # (what ik_only will take)
+    kp_host = kp_glob[lo:hi]  # this rank's clips (kernel-only timing below)
     nq, nb, K = fs.tables.nq, fs.tables.nbody, fs.tables.nsite
     for _ in range(args.warmup):
         stac.ik_only(kp_flat, offsets)
@@ -207,10 +233,15 @@ def run_run_mode(args, rank, local_rank, world, dist):
     q_ms, fk_ms = e[0].elapsed_time(e[1]), float(np.median(fk_ms))
     fk_bytes = C * F * (4 * nq * 2 + 12 * nb + 16 * nb + 12 * K)  # qpos in, normalised qpos + xpos + xquat + marker sites out
     wall = float(np.mean(walls))
-    frames = C * F
+    if dist:  # the slowest rank's wall is the job's
+        tmax = torch.tensor([wall], device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+    frames = (hi - lo) * F  # frames this rank solved (every rank the same number)
+    assert data.qpos.shape[0] == frames, (data.qpos.shape, frames)
     gpu_side = phases.get("q_phase_and_fk_kernels_s", 0.0)
     line = {
-        "metric": "frames/sec Stac.ik_only end to end (rodent, 23 kp, all outputs)", "value": world * frames / wall, "unit": "frames/s",
+        "metric": "frames/sec Stac.ik_only end to end (rodent, 23 kp, all outputs)", "value": job_value(shape, 1, wall), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * wall, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -274,7 +305,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step (--scaling strong: frames of the WHOLE job)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak = --frames frames on every GPU (the default bench); strong = --frames frames in total, their clips "
+                         "split over the ranks (BASELINE configs[3]: --scaling strong --frames 1000000 --frames-per-clip 250)")
     ap.add_argument("--frames-per-clip", type=int, default=1)
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,14 +351,29 @@ def main():
 
     fs, cfg = load_setup(args.model)
     F = args.frames_per_clip
-    C = args.frames // F
+    strong = args.scaling == "strong"
+    shape = job_shape(args.scaling, args.frames, F, rank, world)
+    C_total, lo, hi, C = shape["clips_total"], shape["lo"], shape["hi"], shape["clips_rank"]
     eng = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), lanes_per_chain=args.lanes,
                  device=f"cuda:{local_rank}", solver=args.solver, lm_maxiter=args.lm_maxiter)
     # synthetic batch (seeded per rank), generated with the engine's own FK, then offsets fixed
     eng.set_site_pos(synth_offsets(fs))
     fk = lambda q: eng.fk(q, want=("site_xpos",))["site_xpos"].cpu().numpy()
-    kp_host, _ = synth_keypoints(fs, fk, C, F, seed=1000 * rank, noise_seed=1000 * rank + 1)
-    kp = torch.as_tensor(kp_host).to(eng.device)
+    if strong:
+        # one global dataset whatever the number of ranks: blocks of kBlock clips, block b seeded by b; a rank generates the
+        # blocks its shard touches (uploaded block by block: 1 M frames are 276 MB of keypoints)
+        kBlock = 500
+        parts = []
+        for b in range(lo // kBlock, (max(hi, lo + 1) - 1) // kBlock + 1):
+            nb_ = min(kBlock, C_total - b * kBlock)
+            blk, _ = synth_keypoints(fs, fk, nb_, F, seed=100 + 2 * b, noise_seed=101 + 2 * b)
+            parts.append(torch.as_tensor(blk[max(lo - b * kBlock, 0):max(min(hi - b * kBlock, nb_), 0)]).to(eng.device))
+        kp = torch.cat(parts) if parts else torch.empty((0, F, 3 * fs.tables.nsite), device=eng.device)
+        kp_host = kp[:2000].cpu().numpy()  # (cpu_baseline's sample)
+        assert kp.shape[0] == C
+    else:
+        kp_host, _ = synth_keypoints(fs, fk, C, F, seed=1000 * rank, noise_seed=1000 * rank + 1)
+        kp = torch.as_tensor(kp_host).to(eng.device)
     out = None
 
     def step():
@@ -354,8 +403,8 @@ def main():
         elapsed = float(tmax.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    frames_step = C * F
-    value = world * frames_step * args.steps / elapsed
+    frames_step = C * F  # this rank's frames per step
+    value = job_value(shape, args.steps, elapsed)  # whole-job frames over the slowest rank's time
     cnt = out["counters"].to(torch.float64).sum(dim=(0, 1)).cpu().numpy()
     err = torch.linalg.norm((eng.fk(out["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
                              - kp.reshape(-1, fs.tables.nsite, 3)), dim=-1)
@@ -379,15 +428,17 @@ def main():
         "metric": "frames/sec STAC pose-fit (rodent, 23 kp)" if args.model == "rodent" else f"frames/sec STAC pose-fit ({args.model}, {fs.tables.nsite} kp)",
         "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{'BASELINE configs[1]: rodent.xml' if args.model == 'rodent' else args.model + ' model'}, "
-                        f"{fs.tables.nsite} keypoints, {frames_step} synthetic frames per GPU, "
+            "workload": (f"BASELINE configs[3]: rodent.xml, {C_total * F} synthetic frames in total as {C_total} clips split over "
+                         f"{world} GPU(s) (strong scaling; this rank: {C} clips), " if strong and args.model == "rodent" else
+                         f"{'BASELINE configs[1]: rodent.xml' if args.model == 'rodent' else args.model + ' model'}, ")
+                        + f"{fs.tables.nsite} keypoints, {frames_step} synthetic frames per GPU, "
                         f"q_phase only ({'root opt + ' if fs.do_root_opt else ''}full + {len(fs.part_masks)} part PG solves per frame), n_frames_per_clip={F} "
                         f"({C} independent chains), FTOL={cfg['FTOL']}, N_ITER_Q={cfg['N_ITER_Q']}, "
                         + ("solver=pg (parity mode)" if args.solver == "pg" else f"solver=lm, at most {args.lm_maxiter} steps per solve (NOT the reference's algorithm; marker-space quality only)"),
-            "frames_per_gpu": frames_step, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
-            "parallelism": f"clips sharded over {world} GPU(s), no data-path collective",
+            "frames_per_gpu": frames_step, "frames_total": C_total * F, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
+            "parallelism": f"clips sharded over {world} GPU(s) (dist.shard_range: contiguous blocks), no data-path collective",
             "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
             "iters_per_frame": cnt[0] / frames_step, "ls_evals_per_frame": cnt[1] / frames_step,
             "grad_evals_per_frame": cnt[2] / frames_step,
@@ -442,7 +493,7 @@ def main():
         probe = offset_phase_exchange_probe(part, lambda red: eng.m_finish(red, off_now, is_reg, 1.0)[0])
         line["config"]["offset_phase_exchange"] = dict(probe, note="one all-reduce (all-gather + fixed-order sum) of the offset "
                                                        "phase's partial sums per calibration iteration; --mode fit runs the whole calibration")
-    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and F == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and F == 1 and not args.no_extras and not strong:
         # BASELINE configs[1] with the reference's DEFAULT chaining (configs/stac/stac.yaml:9, n_frames_per_clip = 250):
         # the same number of frames as 40 warm-started clips -- latency mode, one chain per workgroup.  Never `value`.
         Fc = 250
@@ -469,7 +520,7 @@ def main():
             "iters_per_frame": ccnt[0] / (Cc * Fc), "us_per_pg_iteration": c_ms * 1e3 / (ccnt[0] / Cc),
             "marker_rmse_mm": float(torch.sqrt((cerr ** 2).mean()).item() * 1e3),
             "note": "each clip is one serial chain of 250 x ~410 PG iterations: speculative latency mode, 4 wavefronts per chain"}
-    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and not args.no_extras:
+    if rank == 0 and world == 1 and args.solver == "pg" and args.model == "rodent" and not args.no_extras and not strong:
         # the north star words the q_phase as a Levenberg-Marquardt update; the reference runs projected gradient (the
         # `value` above, parity mode).  The optional LM solver on the same resident batch, for the record -- never `value`.
         lm = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), device=f"cuda:{local_rank}",

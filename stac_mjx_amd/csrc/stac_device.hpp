@@ -254,6 +254,13 @@ enum : int { ST_VG_Y = 0, ST_LS = 1, ST_VG_X = 2, ST_DONE = 3, ST_SPEC = 4, ST_W
         if (a.prof && lane == 0)                                                          \
             for (int i = 0; i < 14; ++i) atomicAdd(a.prof + i, pacc[i]);                  \
     } while (0)
+#elif defined(STAC_MARK)  // developer builds: phase boundaries as comments in the assembly listing (no instruction)
+#define PROF_DECL
+#define PROF_TRIP
+#define PROF_ROOT(isroot)
+#define PROF_LM_END
+#define PROF_TICK(i) asm volatile("; TICK " #i)
+#define PROF_FLUSH(a)
 #else
 #define PROF_DECL
 #define PROF_TRIP

@@ -1355,7 +1355,9 @@ __global__ __launch_bounds__(64) void fk_kernel(FullModel M, const float *qpos, 
     float *slot = lds + t;
     V3 pos = {0.f, 0.f, 0.f};
     Q4 quat = {1.f, 0.f, 0.f, 0.f};
-    float qnext = q[brec[13]], qnext2 = q[brec[14]];  // the first two joints visited (0 in a model without joints: any readable word)
+    // the first two joints visited (a model without joints -- wave-uniform -- has no qpos row to read from)
+    float qnext = 0.0f, qnext2 = 0.0f;
+    if (M.nq > 0) { qnext = q[brec[13]]; qnext2 = q[brec[14]]; }
     for (int b = 0; b < M.nbody; ++b) {
         KInt br = brec + 16 * b;
         KFlt bf = (KFlt)br;

@@ -24,18 +24,8 @@ def pytest_configure(config):
     _install_scratch_poison()
 
 
-POISON_SO = ROOT / "tests" / "tools" / "libpoison.so"
-
-
-def build_poison_tool():
-    """tests/tools/poison_scratch.hip -> tests/tools/libpoison.so (also built by __graft_entry__.build())."""
-    import subprocess
-
-    src = ROOT / "tests" / "tools" / "poison_scratch.hip"
-    if not POISON_SO.exists() or POISON_SO.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-shared", "-fPIC", str(src), "-o", str(POISON_SO)],
-                       check=True)
-    return POISON_SO
+sys.path.insert(0, str(ROOT / "tests" / "tools"))
+from build_tools import POISON_SO, build_poison_tool  # noqa: E402,F401  (tests/tools/build_tools.py)
 
 
 def _install_scratch_poison():
