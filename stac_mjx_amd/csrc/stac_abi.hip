@@ -17,8 +17,10 @@
 
 namespace stac {
 bool q_phase_has_variant(int G, int nq, int wpe);
+bool q_phase_has_lean_variant(int G, int nq, int wpe, int spec);
+bool q_phase_lean_conditions(const QArgs &a, int G);
 hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
-                          int *capacity_out);
+                          int *capacity_out, bool lean);
 hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
                              int *capacity_out);
 int lm_waves_per_simd(int G, int nq);
@@ -94,6 +96,9 @@ struct stac_model {
     std::vector<float> h_aj_pos;
     int n_mlev_root = 0;        // micro-levels of the root-pass program currently in the blob (0 = none)
     int n_run_root = 0;         // of which the leading ones have work (n_mlev_root is padded to an even count)
+    PlanHeader h3{};            // h with the chain layout of a lean launch (split kinematics, PlanHeader::fk3); valid when h.fk3
+    int fk3r[5] = {0, 0, 0, 0, 0};  // the pruned FK3 program currently in the blob: n1, n2, n3, m1, m3 (n3 = 0: none)
+    std::vector<float> h_bpos;  // body_pos of the active bodies, by slot
     int32_t *d_lm_tab = nullptr;
     size_t lm_tab_words = 0;
     std::vector<int32_t> lm_tab_cache;
@@ -333,6 +338,147 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
     if (n_run_out) *n_run_out = std::max(t_end, 1);  // steps with work (the records are padded to an even count)
     if (uniform_out) *uniform_out = uniform ? 1 : 0;
     return prog;
+}
+
+// ---- split kinematics (PlanHeader::fk3): the three tables of a program ---------------------------------------------------------
+// P1 runs one quaternion product per active hinge, P3 one addition per rotation that is not identically zero; both are list-
+// scheduled (longest remaining path first) on four lane positions.  A position continues with the successor of its last
+// operation where there is one -- the running value stays in its registers --, any other operation "restarts" from the LDS
+// entry of its predecessor.  Returns false if the program does not fit (more than 32 steps, offsets beyond 16 bits).
+struct Fk3Program {
+    std::vector<int32_t> words;   // T1 [(cap1 + 2) * 4][4], T2 [cap2][4], T3 [cap3 * 4], site words [K], joint words [naj]
+    int n1 = 0, n2 = 0, n3 = 0;
+    uint32_t m1 = 0, m3 = 0;
+};
+struct Fk3Op { int prev; int height; int t = -1, pp = -1; bool restart = false; };
+static int fk3_schedule(std::vector<Fk3Op> &ops) {  // returns the number of steps
+    const int n = (int)ops.size(), W = 4;
+    for (int i = n - 1; i >= 0; --i) {
+        ops[i].height = std::max(ops[i].height, 1);
+        if (ops[i].prev >= 0) ops[ops[i].prev].height = std::max(ops[ops[i].prev].height, ops[i].height + 1);
+    }
+    std::vector<int> last(W, -2);  // last operation of every position (-2: none yet)
+    int done = 0, t = 0;
+    for (; done < n; ++t) {
+        std::vector<char> taken(W, 0);
+        for (int pp = 0; pp < W; ++pp) {  // continue where a successor exists
+            if (last[pp] < 0) continue;
+            int best = -1;
+            for (int i = 0; i < n; ++i)
+                if (ops[i].t < 0 && ops[i].prev == last[pp] && (best < 0 || ops[i].height > ops[best].height)) best = i;
+            if (best >= 0) { ops[best].t = t; ops[best].pp = pp; taken[pp] = 1; last[pp] = best; ++done; }
+        }
+        for (int pp = 0; pp < W; ++pp) {  // free positions take the most urgent operation whose predecessor is finished
+            if (taken[pp]) continue;
+            int best = -1;
+            for (int i = 0; i < n; ++i)
+                if (ops[i].t < 0 && (ops[i].prev < 0 || (ops[ops[i].prev].t >= 0 && ops[ops[i].prev].t < t)) &&
+                    (best < 0 || ops[i].height > ops[best].height))
+                    best = i;
+            if (best >= 0) { ops[best].t = t; ops[best].pp = pp; ops[best].restart = true; taken[pp] = 1; last[pp] = best; ++done; }
+        }
+        if (t > 4 * n + 8) return -1;
+    }
+    return t;
+}
+static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const char *need, int cap1, int cap2, int cap3, Fk3Program &out) {
+    const int nab = h3.nab, naj = h3.naj, K = h3.K;
+    auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    auto nz3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
+    // quaternion node of every body (= its last joint, else its parent's) and the pre-joint node of every joint
+    std::vector<int> fin(nab, 0), pre(naj, 0);
+    for (int s = 0; s < nab; ++s) {
+        const int ps = m->h_ab_parent[s] - 1;
+        int cur = ps >= 0 ? fin[ps] : 0;
+        for (int i = 0; i < m->h_ab_jnum[s]; ++i) { const int j = m->h_ab_jadr[s] + i; pre[j] = cur; cur = j; }
+        fin[s] = cur;
+    }
+    // P1: one product per needed hinge
+    std::vector<Fk3Op> o1;
+    std::vector<int> j_of1, op_of_j(naj, -1);
+    for (int s = 0; s < nab; ++s) {
+        if (need && !need[s]) continue;
+        for (int i = 0; i < m->h_ab_jnum[s]; ++i) {
+            const int j = m->h_ab_jadr[s] + i;
+            if (j == 0) continue;  // the free root: its quaternion comes from the pre-pass
+            op_of_j[j] = (int)o1.size();
+            o1.push_back(Fk3Op{pre[j] == 0 ? -1 : op_of_j[pre[j]], 0});
+            j_of1.push_back(j);
+        }
+    }
+    // P3: the additions, in the order of the step program (body_pos, then per joint anchor and position)
+    struct Rot { int qnode; float v[3]; };
+    std::vector<Fk3Op> o3;
+    std::vector<Rot> rot;  // one per P3 operation
+    std::vector<int> body_op(nab, -1), anchor_op(naj, -1);
+    for (int s = 0; s < nab; ++s) {
+        if (need && !need[s]) continue;
+        const int ps = m->h_ab_parent[s] - 1;
+        int cur = ps >= 0 ? body_op[ps] : -1;
+        const float *bp = m->h_bpos.data() + 3 * s;
+        if (s != 0 && nz3(bp)) {
+            o3.push_back(Fk3Op{cur, 0});
+            rot.push_back(Rot{ps >= 0 ? fin[ps] : 0, {bp[0], bp[1], bp[2]}});
+            cur = (int)o3.size() - 1;
+        }
+        for (int i = 0; i < m->h_ab_jnum[s]; ++i) {
+            const int j = m->h_ab_jadr[s] + i;
+            if (j == 0) { cur = -1; anchor_op[j] = -1; continue; }  // free root: position = qpos[0:3]
+            const float *jp = m->h_aj_pos.data() + 3 * j;
+            if (nz3(jp)) {
+                o3.push_back(Fk3Op{cur, 0});
+                rot.push_back(Rot{pre[j], {jp[0], jp[1], jp[2]}});        // anchor = rotate(jpos, prequat) + pos
+                cur = (int)o3.size() - 1;
+                anchor_op[j] = cur;
+                o3.push_back(Fk3Op{cur, 0});
+                rot.push_back(Rot{j, {-jp[0], -jp[1], -jp[2]}});          // pos = anchor - rotate(jpos, quat): rotate is odd in v
+                cur = (int)o3.size() - 1;
+            } else {
+                anchor_op[j] = cur;
+            }
+        }
+        body_op[s] = cur;
+    }
+    const int n1 = fk3_schedule(o1), n3 = fk3_schedule(o3);
+    const int n2 = ((int)o3.size() + 31) & ~31;
+    if (n1 < 0 || n3 < 0 || n1 > 32 || n3 > 32 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;
+    const int root_slot = cap3 * 4, sink_slot = cap3 * 4 + 1;
+    auto pbw = [&](int op) { return h3.c3_pb + 3 * (op < 0 ? root_slot : o3[op].t * 4 + o3[op].pp); };
+    auto qbw = [&](int node) { return h3.c3_qb + 4 * node; };
+    if (h3.stride3 >= 65536) return false;
+    out.n1 = std::max(n1, 0); out.n2 = n2; out.n3 = n3; out.m1 = out.m3 = 0;
+    // T1: row 0 is a prologue (only its ql word counts), row t + 1 is step t: {ql word of the position's NEXT step, out word,
+    // restart word | -1, -}; one more row behind the last step (P1 fetches a row ahead)
+    out.words.assign((size_t)16 * (cap1 + 2) + 4 * (size_t)cap2 + 4 * (size_t)cap3 + K + naj, 0);
+    int32_t *T1 = out.words.data(), *T2 = T1 + 16 * (cap1 + 2), *T3 = T2 + 4 * cap2, *SW = T3 + 4 * cap3, *JW = SW + K;
+    for (int i = 0; i < 4 * (cap1 + 2); ++i) { T1[4 * i] = h3.c3_ql; T1[4 * i + 1] = qbw(naj); T1[4 * i + 2] = -1; }  // idle: any ql, sink
+    for (size_t i = 0; i < o1.size(); ++i) {
+        const int j = j_of1[i];
+        T1[4 * (o1[i].t * 4 + o1[i].pp)] = h3.c3_ql + 4 * j;  // (the row in front of the step's own)
+        int32_t *r = T1 + 4 * ((o1[i].t + 1) * 4 + o1[i].pp);
+        r[1] = qbw(j);
+        if (o1[i].restart) { r[2] = qbw(pre[j]); out.m1 |= 1u << o1[i].t; }
+    }
+    for (int i = 0; i < cap2; ++i) { T2[4 * i + 3] = qbw(0) | (h3.c3_pb + 3 * sink_slot) << 16; }  // no-op: rotate(0, root quaternion) into the sink
+    for (size_t i = 0; i < o3.size(); ++i) {
+        int32_t *r = T2 + 4 * i;
+        for (int c = 0; c < 3; ++c) r[c] = f2i(rot[i].v[c]);
+        r[3] = qbw(rot[i].qnode) | pbw((int)i) << 16;
+    }
+    for (int i = 0; i < 4 * cap3; ++i) T3[i] = -1;
+    for (size_t i = 0; i < o3.size(); ++i)
+        if (o3[i].restart) { T3[o3[i].t * 4 + o3[i].pp] = pbw(o3[i].prev); out.m3 |= 1u << o3[i].t; }
+    for (int k = 0; k < K; ++k) {
+        const int sl = m->h_site_slot[k];
+        if (need && !need[sl]) { SW[k] = pbw(-1) | qbw(0) << 16; continue; }  // (a site the root passes do not weigh: any valid entry)
+        SW[k] = pbw(body_op[sl]) | qbw(fin[sl]) << 16;
+    }
+    // per joint: word of its anchor | word of its pre-joint quaternion << 16 (the gradient pass; full program only)
+    for (int j = 0; j < naj; ++j) JW[j] = need ? 0 : (pbw(anchor_op[j]) | qbw(pre[j]) << 16);
+    if (m->dbg.verbose)
+        fprintf(stderr, "[stac] FK3 program%s: %d products in %d steps, %d rotations, %d additions in %d steps\n", need ? " (root passes)" : "",
+                (int)o1.size(), n1, (int)o3.size(), (int)o3.size(), n3);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -592,12 +738,67 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.c_kp = o; o += 3 * K;
     h.stride_lds = stride_of(o) + std::max(m->dbg.stride_add, 0);
 
+    m->h_brec = brec; m->h_lev_adr = lev_adr; m->h_ab_jadr = ab_jadr; m->h_ab_jnum = ab_jnum; m->h_xf = xf;
+    m->h_aj_pos = aj_pos;
+    m->h_bpos.resize((size_t)3 * nab);
+    for (int s = 0; s < nab; ++s)
+        for (int i = 0; i < 3; ++i) m->h_bpos[3 * s + i] = brec[s].pos[i];
+    bool any_bquat = false;
+    for (int s = 0; s < nab; ++s) any_bquat = any_bquat || !(brec[s].flags & 1);
+    {   // Split kinematics (PlanHeader::fk3; stac_plan.hpp): a free root at qpos 0 .. 6 on the ONE top-level active body, hinges
+        // below it, no oriented body.  The lean kernels run nothing else, so a model without it takes the generic kernels.
+        h.fk3 = 0;
+        bool ok = naj >= 1 && aj_type[0] == STAC_JNT_FREE && aj_qadr[0] == 0 && !any_bquat && nqj == 1 && !has_ball &&
+                  getenv("STAC_HIP_NOFK3") == nullptr;
+        for (int j = 1; j < naj && ok; ++j) ok = aj_type[j] == STAC_JNT_HINGE;
+        for (int s = 1; s < nab && ok; ++s) ok = ab_parent[s] != 0;
+        if (ok) {
+            PlanHeader g = h;  // the lean chain layout: regions of whole 4-word groups, stride 4 x odd (16-byte aligned entries)
+            // capacities of a program area: the full program's own sizes (a pruned program is a sub-DAG: it is checked against them)
+            Fk3Program probe;
+            g.c3_qb = 0; g.c3_pb = 0; g.c3_ql = 0; g.stride3 = 1;
+            ok = build_fk3_program(m, g, nullptr, 32, 4096, 32, probe);
+            if (ok) {
+                g.fk3_cap1 = std::max(probe.n1, 1); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 1);
+                int o3 = 0;
+                g.c3_qb = o3; o3 += (naj + 1) * 4;                       // (+ 1: the sink of idle P1 positions)
+                g.c3_pb = o3; o3 += ((g.fk3_cap3 * 4 + 4) * 3 + 3) & ~3;  // (step, position) slots, root position, sink, slack of the prefetch
+                g.c3_ql = o3; o3 += std::max(naj * 4, (h.nrange * kXf + 3) & ~3);
+                g.c_rw = g.c3_ql;                                         // a full trip's range sums go where the joint-local quaternions were
+                g.c3_rw0 = o3; o3 += 8;
+                g.c_jn = o3; o3 += 4;
+                g.c_qsv = o3; o3 += 4 * nqj;
+                g.c_sw = o3; o3 += (std::max(K * kXf, h.nqpad + kXf) + 3) & ~3;
+                g.c_sink = g.c_sw + std::max(K * kXf, h.nqpad + kXf) - kXf;
+                g.c_gg = g.c_qe = g.c_sw;
+                g.c_bx = g.c_ja = 0;  // (unused by the lean kernels)
+                const int q4 = (o3 + 3) / 4;
+                g.stride3 = 4 * (q4 | 1);
+                if ((g.stride3 / 4) % 8 == 0) g.stride3 += 8;  // (never a multiple of 32 words: the chains of a wavefront on different banks)
+                g.stride_regs = g.stride_lds = g.stride3;
+                g.stride_forced = 1;  // (q_chain_stride takes it as it is)
+                Fk3Program full;
+                ok = build_fk3_program(m, g, nullptr, g.fk3_cap1, g.fk3_cap2, g.fk3_cap3, full);
+                if (ok) {
+                    g.fk3 = 1;
+                    g.fk3_n1 = full.n1; g.fk3_n2 = full.n2; g.fk3_n3 = full.n3; g.fk3_m1 = (int32_t)full.m1; g.fk3_m3 = (int32_t)full.m3;
+                    g.off3_prog = put_raw(full.words.data(), full.words.size());
+                    g.off3_site = g.off3_prog + 16 * (g.fk3_cap1 + 2) + 4 * g.fk3_cap2 + 4 * g.fk3_cap3;
+                    std::vector<int32_t> blank3(full.words.size(), 0);
+                    g.off3_root = put_raw(blank3.data(), blank3.size());
+                    // what both layouts share
+                    const int32_t keep[] = {g.fk3, g.off3_site, g.off3_prog, g.off3_root, g.fk3_n1, g.fk3_n2, g.fk3_n3, g.fk3_m1, g.fk3_m3,
+                                            g.fk3_cap1, g.fk3_cap2, g.fk3_cap3};
+                    h.fk3 = keep[0]; h.off3_site = keep[1]; h.off3_prog = keep[2]; h.off3_root = keep[3]; h.fk3_n1 = keep[4]; h.fk3_n2 = keep[5];
+                    h.fk3_n3 = keep[6]; h.fk3_m1 = keep[7]; h.fk3_m3 = keep[8]; h.fk3_cap1 = keep[9]; h.fk3_cap2 = keep[10]; h.fk3_cap3 = keep[11];
+                    h.c3_ql = g.c3_ql; h.c3_qb = g.c3_qb; h.c3_pb = g.c3_pb; h.c3_rw0 = g.c3_rw0; h.stride3 = g.stride3;
+                    m->h3 = g;
+                }
+            }
+        }
+    }
     {   // FK program (FkStep records, see stac_plan.hpp); a second area of the same size takes the pruned program of
         // the root passes, which depends on the call's trunk keypoints (fill_root_program)
-        m->h_brec = brec; m->h_lev_adr = lev_adr; m->h_ab_jadr = ab_jadr; m->h_ab_jnum = ab_jnum; m->h_xf = xf;
-        m->h_aj_pos = aj_pos;
-        bool any_bquat = false;
-        for (int s = 0; s < nab; ++s) any_bquat = any_bquat || !(brec[s].flags & 1);
         h.fk_rec_words = any_bquat ? 16 : 12;
         {   // header of a program area: a flag word per micro-level (of the full program: a pruned one has fewer),
             // then the first step's ql offset per position
@@ -621,6 +822,12 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.total_words = (int)B.size();
 
     h.chain_stride = h.stride_lds;
+    if (h.fk3) {  // the lean layout's copy of everything that was settled after it was made
+        PlanHeader &g = m->h3;
+        g.fk_rec_words = h.fk_rec_words; g.n_mlev_hdr = h.n_mlev_hdr; g.fk_hdr_words = h.fk_hdr_words; g.off_fkstep = h.off_fkstep;
+        g.off_fkroot = h.off_fkroot; g.n_mlev = h.n_mlev; g.fk_uniform = h.fk_uniform; g.total_words = h.total_words;
+        g.chain_stride = g.stride3;
+    }
     return STAC_OK;
 }
 
@@ -629,7 +836,7 @@ static void rebase_plan_offsets(PlanHeader &h) {
     const int sk = h.plan_skip;
     if (sk <= 0) return;
     int32_t *offs[] = {&h.off_joint, &h.off_site, &h.off_range, &h.off_lb, &h.off_ub, &h.off_qpos0, &h.off_quat_adr,
-                       &h.off_active, &h.off_fkstep, &h.off_fkroot};
+                       &h.off_active, &h.off_fkstep, &h.off_fkroot, &h.off3_site, &h.off3_prog, &h.off3_root};
     for (int32_t *o : offs) *o -= sk;
     h.off_lev_adr = h.off_body = 0;  // not staged (nothing of a program launch reads them)
 }
@@ -673,11 +880,11 @@ constexpr long kSpec4MinChains = 1L << 40;
 // per CU.  LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not
 // fit a CU).
 struct QShape { int wpb, wpe, waves_per_cu; };
-static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_needed = -1) {
+static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_needed = -1, bool lean = false) {
     constexpr size_t kGranule = 1280;
     QShape best{0, 2, 0};
     for (int wpe = 2; wpe <= 4; ++wpe) {
-        if (!q_phase_has_variant(G, h.nq, wpe)) continue;  // (stac_kernels.hip, STAC_Q_SHAPES: only shapes that pass the spill gate are built)
+        if (!(lean ? q_phase_has_lean_variant(G, h.nq, wpe, 0) : q_phase_has_variant(G, h.nq, wpe))) continue;  // (stac_kernels.hip, STAC_Q_SHAPES: only shapes that pass the spill gate are built)
         for (int wpb = 1; wpb <= (wpe == 3 ? 10 : 8); ++wpb) {
             size_t lds = q_lds_bytes(h, G, nkinds, wpb);
             if (lds > kLdsPerCu) break;
@@ -871,28 +1078,29 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 // i.e. the latency mode up to about 2.3 x its resident capacity, then 32 lanes until the 16-lane kernel has
 // about 45 % of its slots filled (8 and 4 lanes only on request: with the LDS footprint of a chain they cannot
 // keep two waves per SIMD resident).  Returns 0 for the latency mode.
-static int pick_lanes(const stac_model *m, int requested, int nchains, int nkinds, bool spec_allowed, int frames) {
+static int pick_lanes(const stac_model *m, const PlanHeader &mh, int requested, int nchains, int nkinds, bool spec_allowed, int frames) {
+    // (mh: the model's header with the chain layout this call's launches will most likely have -- lean or generic)
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
-        const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR)  // one chain per wave
-                                                  : pick_spec_shape(m->h, 32, nkinds);
+        const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(mh, kLatG, nkinds, -1, kLatR)  // one chain per wave
+                                                  : pick_spec_shape(mh, 32, nkinds);
         // Measured crossover against the throughput kernel (rodent, profiles/r03/shape_sweep.txt): 1.8 x the resident chains
         // for single-frame clips, 2.3 x for two or three frames, 2.6 x from four frames on (the longer a clip, the less
         // of it are the root solves that the throughput kernel runs as fast trips)
         const long x10 = frames <= 1 ? 18 : (frames < 4 ? 23 : 26);
         if (ss.resident && (long)nchains * 10 <= ss.resident * x10) return 0;
     }
-    const QShape s16 = pick_shape(m->h, 16, nkinds);
+    const QShape s16 = pick_shape(mh, 16, nkinds);
     {   // Models whose chains are so large that 16-lane groups leave a wavefront or less per SIMD (mouse: 6.9 KB of LDS per chain,
         // three 4-chain wavefronts per CU): 32-lane groups hold MORE chains per CU there (seven 2-chain wavefronts) and halve
         // the rounds of every per-coordinate and per-joint phase -- 27.3 k -> 36.4 k frames/s on 10 000 mouse frames.
-        const QShape s32 = pick_shape(m->h, 32, nkinds);
+        const QShape s32 = pick_shape(mh, 32, nkinds);
         if (s16.wpb && s32.wpb && s32.waves_per_cu * 2 > s16.waves_per_cu * 4 && m->h.max_width * 4 <= 32 &&
             (long)nchains * 100 > (long)s32.waves_per_cu * kCus * 2 * 45)
             return 32;
     }
     if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 25) return 16;  // (from a quarter of the resident slots on: 16 lanes beat 32 at every measured size above the latency kernel's range)
-    if (nchains > 2500 && pick_shape(m->h, 32, nkinds).wpb) return 32;
+    if (nchains > 2500 && pick_shape(mh, 32, nkinds).wpb) return 32;
     return 64;
 }
 
@@ -932,7 +1140,27 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
 #endif
     // (clip length for the latency / throughput crossover; without root optimisation -- the tethered fly -- a single-frame clip
     //  has no root solves for the throughput kernel to run as fast trips: counted like a two-frame clip, measured)
-    int G = pick_lanes(m, p->lanes_per_chain, nchains, nkinds, !a.single, a.single ? 1 : (a.do_root_opt ? a.F : std::max(a.F, 2)));
+    // Which chain layout a launch gets: the lean kernels (split kinematics) have their own (PlanHeader::fk3, stac_model::h3).  Decided per
+    // launch from the launch's own flags and lanes (lean_for); `likely` only serves the shape heuristics before the lanes are known.
+    auto lean_for = [&](QArgs &q, int lanes, int wpe_or_roles, bool spec_launch) {
+        q.h.fk3 = m->h.fk3; q.h.K = m->h.K; q.h.nqj = m->h.nqj; q.h.has_ball = m->h.has_ball;
+        if (dbg.nolean || !m->h.fk3 || !q_phase_lean_conditions(q, lanes)) return false;
+        if (spec_launch) return q_phase_has_lean_variant(lanes, m->h.nq, 2, wpe_or_roles);
+        return q_phase_has_lean_variant(lanes, m->h.nq, 2, 0) || q_phase_has_lean_variant(lanes, m->h.nq, 3, 0);
+    };
+    // a lean launch stages the plan from the joint records up to the split-kinematics tables (the root program only when it is used)
+    auto lean_header = [&](const QArgs &q) {
+        PlanHeader hh = m->h3;
+        hh.plan_skip = m->h.off_joint;
+        const int area = 16 * (hh.fk3_cap1 + 2) + 4 * hh.fk3_cap2 + 4 * hh.fk3_cap3 + hh.K + hh.naj;
+        hh.total_words = (q.do_root_opt && q.fk3r_n3 > 0) ? hh.off3_root + area : hh.off3_root;
+        return hh;
+    };
+    const bool likely_lean = m->h.fk3 && !a.single && !a.bounds && !dbg.nolean && !(dbg.flags >= 0 && dbg.flags != 0);
+    const PlanHeader &mh = likely_lean ? m->h3 : m->h;
+    // (clip length for the latency / throughput crossover; without root optimisation -- the tethered fly -- a single-frame clip
+    //  has no root solves for the throughput kernel to run as fast trips: counted like a two-frame clip, measured)
+    int G = pick_lanes(m, mh, p->lanes_per_chain, nchains, nkinds, !a.single, a.single ? 1 : (a.do_root_opt ? a.F : std::max(a.F, 2)));
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
     // Latency mode: when there are so few chains that each would get a whole wavefront anyway (G = 64), let
@@ -946,7 +1174,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // (measured, rodent, 250-frame clips: DESIGN.md 2.1), else one wavefront per chain
         int sg = kLatG;
         {
-            const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(m->h, 32, nkinds);
+            const SpecShape s64 = pick_spec_shape(mh, 64, nkinds), s32 = pick_spec_shape(mh, 32, nkinds);
             if (s64.resident && (long)nchains <= kSpec64MaxChains) sg = 64;
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
         }
@@ -959,35 +1187,52 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         int sr = (sg == 8 && (long)nchains >= kSpec4MinChains) ? 4 : 8;
         if (sg == 8 && (dbg.specr == 4 || dbg.specr == 8)) sr = dbg.specr;
         if (sg == 16) sr = 4;  // four roles of 16 lanes: one chain per wavefront
-        const SpecShape sh = pick_spec_shape(m->h, sg, nkinds, nchains, sr);
+        a.free0p = free0_ordinal_p1(m, sg);
+        set_hinges_flag(m, a);
+        const bool lean = lean_for(a, sg, sr, true);
+        const PlanHeader hh = lean ? lean_header(a) : m->h;
+        const SpecShape sh = pick_spec_shape(hh, sg, nkinds, nchains, sr);
         if (sh.chains_per_block) {
-            const size_t lds = spec_lds_bytes(m->h, sg, nkinds, sh.chains_per_block, sr);
+            const size_t lds = spec_lds_bytes(hh, sg, nkinds, sh.chains_per_block, sr);
             if (dbg.verbose)
-                fprintf(stderr, "[stac] q_phase: chains=%d speculative, %d roles of %d lanes per chain (%d wavefront(s) per chain), %d chain(s) per workgroup, lds=%zu B/block, resident=%ld\n",
-                        nchains, sr, sg, std::max(sg / 8, 1), sh.chains_per_block, lds, sh.resident);
+                fprintf(stderr, "[stac] q_phase: chains=%d speculative%s, %d roles of %d lanes per chain (%d wavefront(s) per chain), %d chain(s) per workgroup, lds=%zu B/block, resident=%ld\n",
+                        nchains, lean ? " (lean)" : "", sr, sg, std::max(sg / 8, 1), sh.chains_per_block, lds, sh.resident);
             a.mb_words = q_mb_words(nkinds, sg);
-            a.h.chain_stride = q_chain_stride(m->h, sg);
+            a.h = hh;
+            a.h.chain_stride = q_chain_stride(hh, sg);
             // chain queue (see below): more clips than resident chain slots -> the roles of a finished clip take the next
-            long resident = pick_spec_shape(m->h, sg, nkinds, -1, sr).resident / sh.chains_per_block * sh.chains_per_block;
+            long resident = pick_spec_shape(hh, sg, nkinds, -1, sr).resident / sh.chains_per_block * sh.chains_per_block;
             if (dbg.queue > 0 && dbg.queue < nchains) resident = (long)(dbg.queue + sh.chains_per_block - 1) / sh.chains_per_block * sh.chains_per_block;
             if ((long)nchains > resident && dbg.queue != 0) {
                 HIP_TRY(launch_ctl_init(m->d_ctl, 0, 0x7fffffff, 0, 0, (int)resident, s));
                 a.ctl = m->d_ctl; a.queue_slots = (int)resident;
             }
-            a.free0p = free0_ordinal_p1(m, sg);
-            set_hinges_flag(m, a);
             a.perm = nullptr; a.place = nullptr;  // (latency mode: few chains, nothing to balance)
-            e = launch_q_phase(a, sg, sh.waves_per_block, 2, sr, lds, s, &cap);
+            rebase_plan_offsets(a.h);
+            e = launch_q_phase(a, sg, sh.waves_per_block, 2, sr, lds, s, &cap, lean);
+            a.h = m->h;
             a.ctl = nullptr; a.queue_slots = 0;
         }
     }
     for (; !cap && G <= 64; G *= 2) {
+        a.free0p = free0_ordinal_p1(m, G);
+        set_hinges_flag(m, a);
+        const int flags_in = a.flags;
+        const bool lean = lean_for(a, G, 0, false);
+        const PlanHeader &gh = lean ? m->h3 : m->h;
         // The FK program (fixed-size step records, prefetched) costs LDS: stage it only if every level fits the
         // lane group and the workgroups that fit a CU stay the same; else the kernel walks the levels itself.
         const long waves_needed = ((long)nchains * G + 63) / 64;
+        a.h = gh;
         a.h.total_words = m->h.core_words;
         a.h.plan_skip = 0;
-        QShape sh = pick_shape(a.h, G, nkinds, waves_needed);
+        QShape sh{0, 2, 0};
+        if (lean) {
+            a.h = lean_header(a);
+            sh = pick_shape(a.h, G, nkinds, waves_needed, true);
+            if (!sh.wpb) { a.h = m->h; a.flags = flags_in; continue; }
+        } else {
+        sh = pick_shape(a.h, G, nkinds, waves_needed);
         if (!sh.wpb) continue;  // does not fit the LDS with this many chains per wave: widen the group
         a.flags |= 2;
         if (m->h.max_width <= G && !(dbg.flags >= 0 && (dbg.flags & 2))) {
@@ -1008,22 +1253,33 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
                 sh = shp; a.h.total_words = hp.total_words; a.h.plan_skip = hp.plan_skip; a.flags &= ~2;
             }
         }
-        if (dbg.wpe >= 0) sh.wpe = dbg.wpe >= 4 ? 4 : (dbg.wpe == 3 && G == 16) ? 3 : 2;
+        }
+        if (dbg.wpe >= 0) {
+            const int want = dbg.wpe >= 4 ? 4 : (dbg.wpe == 3 && G == 16) ? 3 : 2;
+            if (!lean || q_phase_has_lean_variant(G, m->h.nq, want, 0)) sh.wpe = want;
+        }
         if (dbg.wpb >= 0) {  // developer overrides
             const int ww = dbg.wpb;
             if (ww >= 1 && ww <= (sh.wpe == 3 ? 10 : 8) && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
         }
         if (dbg.verbose)
-            fprintf(stderr, "[stac] q_phase: chains=%d G=%d wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
-                    nchains, G, sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), q_chain_stride(m->h, G), a.h.total_words);
+            fprintf(stderr, "[stac] q_phase: chains=%d G=%d%s wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",
+                    nchains, G, lean ? " (lean)" : "", sh.wpb, sh.wpe, sh.waves_per_cu, q_lds_bytes(a.h, G, nkinds, sh.wpb), q_chain_stride(gh, G), a.h.total_words - a.h.plan_skip);
         a.mb_words = q_mb_words(nkinds, G);
-        a.h.chain_stride = q_chain_stride(m->h, G);
+        a.h.chain_stride = q_chain_stride(gh, G);
+        // the latency kernel that takes the stragglers (hand-off below): lean like this launch where it can be
+        QArgs b0 = a;
+        b0.flags = a.flags & ~2;
+        b0.free0p = free0_ordinal_p1(m, kLatG);
+        set_hinges_flag(m, b0);
+        const bool lean_b = lean_for(b0, kLatG, kLatR, true);
+        const PlanHeader hb = lean_b ? lean_header(b0) : m->h;
         // Straggler hand-off: chains take very different numbers of iterations (the slowest of 10 000 about 1.6x the
         // mean), so the launch would end on a few waves per CU.  Once all but `hcap` chains are done, the rest move to
         // the latency kernel at their next iteration boundary (QArgs::ctl).
         int hcap = 0;
-        if (!a.single && !(a.flags & 3) && m->h.max_width <= kLatG && lat_one_wave_ok(m->h)) {
-            const int spec_cap = (int)pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR).resident;
+        if (!a.single && !(a.flags & 3) && (lean_b || m->h.max_width <= kLatG) && lat_one_wave_ok(m->h)) {
+            const int spec_cap = (int)pick_spec_shape(hb, kLatG, nkinds, -1, kLatR).resident;
             // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
             if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
             if (dbg.handoff >= 0) hcap = spec_cap ? std::min(dbg.handoff, nchains) : 0;
@@ -1037,8 +1293,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             const int per_block = sh.wpb * (64 / G), want = dbg.queue;
             if (!a.single && want < nchains) qslots = (want + per_block - 1) / per_block * per_block;
         }
-        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && m->h.max_width <= kLatG && dbg.handoff < 0 && lat_one_wave_ok(m->h)) {
-            hcap = std::min((int)pick_spec_shape(m->h, kLatG, nkinds, -1, kLatR).resident, nchains / 5);  // with a queue the tail is one round: hand off
+        if (qslots > 0 && hcap == 0 && !(a.flags & 3) && (lean_b || m->h.max_width <= kLatG) && dbg.handoff < 0 && lat_one_wave_ok(m->h)) {
+            hcap = std::min((int)pick_spec_shape(hb, kLatG, nkinds, -1, kLatR).resident, nchains / 5);  // with a queue the tail is one round: hand off
         }
         hcap = std::min(hcap, m->hand_cap);
         // A group that hands its chain off stops taking chains from the queue, so hand-off must not begin while the
@@ -1053,8 +1309,6 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         if (hcap > 0) a.hand = m->d_hand;
         const int root_fast = a.root_fast;
         if ((a.flags & 2) || G < root_fast) a.root_fast = 0;  // root fast trips need the FK program and the root coordinates in register 0
-        a.free0p = free0_ordinal_p1(m, G);
-        set_hinges_flag(m, a);
         const int32_t *perm_in = a.perm;
         int32_t *place_in = a.place;
         {
@@ -1074,31 +1328,32 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         }
         {
             const size_t lds_bytes = q_lds_bytes(a.h, G, nkinds, sh.wpb);
-            const PlanHeader h_keep = a.h;
             rebase_plan_offsets(a.h);
-            e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, lds_bytes, s, &cap);
-            a.h = h_keep;
+            e = launch_q_phase(a, G, sh.wpb, sh.wpe, 0, lds_bytes, s, &cap, lean);
+            a.h = m->h;
         }
         a.root_fast = root_fast;
         a.perm = perm_in; a.place = place_in;
         if (cap && e == hipSuccess && hcap > 0) {
             // second launch: the latency kernel resumes whatever was handed off (waves without an entry exit at once)
-            QArgs b = a;
+            QArgs b = b0;
+            b.ctl = a.ctl; b.hand = a.hand; b.root_fast = root_fast;
+            b.queue_slots = 0; b.perm = nullptr; b.place = nullptr;
             b.resume = 1; b.resume_slots = hcap;
-            b.h = m->h;
-            b.flags = a.flags & ~2;
-            const SpecShape ss = pick_spec_shape(m->h, kLatG, nkinds, hcap, kLatR);
+            b.h = hb;
+            const SpecShape ss = pick_spec_shape(hb, kLatG, nkinds, hcap, kLatR);
             b.mb_words = q_mb_words(nkinds, kLatG);
-            b.h.chain_stride = q_chain_stride(m->h, kLatG);
+            b.h.chain_stride = q_chain_stride(hb, kLatG);
             int cap2 = 0;
-            b.free0p = free0_ordinal_p1(m, kLatG);
-            set_hinges_flag(m, b);
-            e = launch_q_phase(b, kLatG, ss.waves_per_block, 2, kLatR, spec_lds_bytes(m->h, kLatG, nkinds, ss.chains_per_block, kLatR), s, &cap2);
+            const size_t lds2 = spec_lds_bytes(hb, kLatG, nkinds, ss.chains_per_block, kLatR);
+            rebase_plan_offsets(b.h);
+            e = launch_q_phase(b, kLatG, ss.waves_per_block, 2, kLatR, lds2, s, &cap2, lean_b);
             if (!cap2) return fail(STAC_ERR_CAPACITY, "hand-off: the latency kernel does not hold this model");
-            if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel (wpb=%d)\n", hcap, ss.waves_per_block);
+            if (dbg.verbose) fprintf(stderr, "[stac] q_phase: hand-off of up to %d stragglers to the latency kernel%s (wpb=%d)\n", hcap, lean_b ? " (lean)" : "", ss.waves_per_block);
         }
         a.ctl = nullptr; a.hand = nullptr; a.queue_slots = 0;
         if (cap) break;  // an instantiation with this many lanes holds nq
+        a.flags = flags_in;
     }
     if (!cap) return fail(STAC_ERR_CAPACITY, "model exceeds the q_phase kernel limits (160 KiB LDS per CU, nq <= 256)");
     if (e != hipSuccess) return fail(STAC_ERR_HIP, std::string("q_phase launch: ") + hipGetErrorString(e));
@@ -1333,6 +1588,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
 static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enable, int n_root_joints, hipStream_t s) {
     const PlanHeader &h = m->h;
     m->n_mlev_root = 0;
+    for (int &v : m->fk3r) v = 0;
     if (!enable || m->dbg.noprune) return STAC_OK;
     std::vector<char> need(h.nab, 0);
     int n_need = 0;
@@ -1351,6 +1607,15 @@ static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enabl
     // the four-lanes-per-position program stops after its last step with work; the other forms run whole pairs
     m->n_mlev_root = n_mlev;
     m->n_run_root = n_run;
+    if (h.fk3) {  // the same bodies as a split-kinematics program (lean launches)
+        Fk3Program rp;
+        if (build_fk3_program(m, m->h3, need.data(), h.fk3_cap1, h.fk3_cap2, h.fk3_cap3, rp) && rp.n3 > 0) {
+            int32_t *d3 = reinterpret_cast<int32_t *>(m->blob_host.data()) + h.off3_root;
+            std::memcpy(d3, rp.words.data(), rp.words.size() * 4);
+            HIP_TRY(hipMemcpyAsync(m->d_blob + h.off3_root, d3, rp.words.size() * 4, hipMemcpyHostToDevice, s));
+            m->fk3r[0] = rp.n1; m->fk3r[1] = rp.n2; m->fk3r[2] = rp.n3; m->fk3r[3] = (int)rp.m1; m->fk3r[4] = (int)rp.m3;
+        }
+    }
     return STAC_OK;
 }
 
@@ -1452,6 +1717,7 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
     a.n_run_root = do_root_opt ? m->n_run_root : 0;
     a.n_root_joints = n_root_joints;
+    if (do_root_opt && m->h.fk3) { a.fk3r_n1 = m->fk3r[0]; a.fk3r_n2 = m->fk3r[1]; a.fk3r_n3 = m->fk3r[2]; a.fk3r_m1 = m->fk3r[3]; a.fk3r_m3 = m->fk3r[4]; }
     // Root fast trips (QArgs::root_fast): the root coordinates are the first root_dims (<= 8: register 0 of every lane
     // group of 8 or more lanes) and belong to leading joints that share ONE subtree range, whose weighted sites fit a 64-bit mask
     if (do_root_opt && m->n_mlev_root > 0 && n_root_joints >= 1 && n_root_joints < m->h.naj && root_dims <= 8 && K <= 64 && !m->dbg.nofast) {

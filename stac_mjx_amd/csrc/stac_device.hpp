@@ -181,6 +181,9 @@ __device__ __forceinline__ HotHeader pin_header(const KH &h) {  // before the lo
 struct TripHeader : HotHeader {  // + the other PlanHeader fields (references into the kernarg segment)
     KRef<int32_t> nbody, njnt, nab, nlev, nquat, has_ball, off_lev_adr, off_body, off_qpos0, off_quat_adr, off_active, total_words,
         plan_skip, core_words, c_gg, c_kp, c_r2, stride_regs, stride_lds, stride_forced, nst, nqj, kpow2;
+    // split kinematics of the lean kernels (PlanHeader::fk3)
+    KRef<int32_t> fk3, off3_site, off3_prog, off3_root, fk3_n1, fk3_n2, fk3_n3, fk3_m1, fk3_m3, fk3_cap1, fk3_cap2, fk3_cap3, c3_ql, c3_qb,
+        c3_pb, c3_rw0, stride3;
 };
 template <int VPIN, class KH>
 __device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH &k) {  // inside the loop: pinned values + fresh reads
@@ -190,9 +193,11 @@ __device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH
 #undef STAC_PIN
     return TripHeader{t, k.nbody, k.njnt, k.nab, k.nlev, k.nquat, k.has_ball, k.off_lev_adr, k.off_body, k.off_qpos0, k.off_quat_adr,
                       k.off_active, k.total_words, k.plan_skip, k.core_words, k.c_gg, k.c_kp, k.c_r2, k.stride_regs, k.stride_lds,
-                      k.stride_forced, k.nst, k.nqj, k.kpow2};
+                      k.stride_forced, k.nst, k.nqj, k.kpow2,
+                      k.fk3, k.off3_site, k.off3_prog, k.off3_root, k.fk3_n1, k.fk3_n2, k.fk3_n3, k.fk3_m1, k.fk3_m3, k.fk3_cap1, k.fk3_cap2,
+                      k.fk3_cap3, k.c3_ql, k.c3_qb, k.c3_pb, k.c3_rw0, k.stride3};
 }
-static_assert(sizeof(PlanHeader) == (27 + 23) * 4, "TripHeader must list every PlanHeader field");
+static_assert(sizeof(PlanHeader) == (27 + 23 + 17) * 4, "TripHeader must list every PlanHeader field");
 struct HotArgs {  // QArgs fields of every trip (values)
     int32_t single, P, flags, free0p, root_fast, n_mlev_root, n_run_root, n_root_joints, maxls, maxiter, queue_slots, resume;
     uint32_t root_trunk_lo, root_trunk_hi;
@@ -207,6 +212,7 @@ __device__ __forceinline__ HotArgs pin_args(const KA &a) {
     return o;
 }
 struct TripArgs : HotArgs {
+    KRef<int32_t> fk3r_n1, fk3r_n2, fk3r_n3, fk3r_m1, fk3r_m3;
     KRef<const float *> kp, q_init;
     KRef<const uint8_t *> kpw, kpw3;
     KRef<const int32_t *> perm;
@@ -222,7 +228,7 @@ __device__ __forceinline__ TripArgs trip_args(const HotArgs &hot, const KA &k) {
 #define STAC_PIN(f, c) if constexpr (!is_pinned<VPIN, STAC_PINCLASS(c)>()) t.f = k.f;
     STAC_HOT_ARGS_FIELDS(STAC_PIN)
 #undef STAC_PIN
-    return TripArgs{t, k.kp, k.q_init, k.kpw, k.kpw3, k.perm, k.C, k.F, k.root_kp_idx, k.do_root_opt, k.ctl, k.hand, k.qpos_out, k.err_out,
+    return TripArgs{t, k.fk3r_n1, k.fk3r_n2, k.fk3r_n3, k.fk3r_m1, k.fk3r_m3, k.kp, k.q_init, k.kpw, k.kpw3, k.perm, k.C, k.F, k.root_kp_idx, k.do_root_opt, k.ctl, k.hand, k.qpos_out, k.err_out,
                     k.counters_out, k.q_carry_out};
 }
 
@@ -924,6 +930,140 @@ __device__ __forceinline__ void fk_chain(const HT &H, const float *P, float *CBc
     } else {
         fk_levels(H, P, CBc, lf, gf, active, store_ja);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split kinematics of the lean kernels (PlanHeader::fk3; tables: stac_abi.hip, build_fk3_program)
+// ------------------------------------------------------------------------------------------------
+// The step program above runs, per body and joint, pos += rotate(bpos, q); anchor = rotate(jpos, q) + pos; q = q * ql;
+// pos = anchor - rotate(jpos, q) as ONE serial chain of ~60-instruction steps.  With a free root and only hinges below it the
+// quaternions do not depend on the positions, so the same operations -- same operands, same order per result: bit-identical --
+// are issued as three passes of which only the cheap ones are serial:
+//   P1  q_j = q_pre(j) * ql_j                 four lanes per product; the running quaternion is the DPP operand, the signed
+//                                             permutations of ql (known before the chain starts) are prepared beside it
+//   P2  r = rotate(v, q_node)                 one lane per rotation (the scalar code's own sequence), all lanes busy
+//   P3  p = p + r                             one addition per rotation, in place in the rotation's slot; three lanes per path
+// A position of P1 / P3 that has no work in a step multiplies / adds whatever its idle record points at and stores to a sink:
+// its running value is garbage until its next path begins, and a path always begins with a restart (a select, not arithmetic).
+struct Fk3Lane {
+    int pp, c;       // lane position (0 .. 3) and component (P1: w, x, y, z; P3: -, x, y, z)
+    int m1, m2, m3;  // sign masks of the lane's row of the quaternion product (as FkQuadLane)
+};
+__device__ __forceinline__ Fk3Lane fk3_lane(const int lf) {
+    Fk3Lane L;
+    L.pp = lf >> 2;
+    L.c = lf & 3;
+    const int sgn = (int)0x80000000u;
+    L.m1 = (L.c == 0 || L.c == 2) ? sgn : 0;
+    L.m2 = (L.c == 0 || L.c == 3) ? sgn : 0;
+    L.m3 = (L.c == 0 || L.c == 1) ? sgn : 0;
+    return L;
+}
+// component c of q * ql from the lane's component of each: r_c = q.w R0 + q.x R1 + q.y R2 + q.z R3 with R_k = +-ql_(c ^ k)
+// (qmul's own products in qmul's own order: the signs sit on the ql factors, fma(-a, b, c) == fma(a, -b, c)).  Hazards: ql comes
+// from LDS; qc -- the DPP operand of the products -- may have been written by the VALU instruction in front of the block: the
+// three permutations of ql stand between (tests/test_isa_hazards.py checks the distance in the binary).
+__device__ __forceinline__ float fk3_qmul(const float qc, const float ql, const Fk3Lane &L) {
+    float r, R1, R2, R3;
+    asm("v_xor_b32_dpp %1, %5, %6" STAC_DPP("1,0,3,2")
+        "v_xor_b32_dpp %2, %5, %7" STAC_DPP("2,3,0,1")
+        "v_xor_b32_dpp %3, %5, %8" STAC_DPP("3,2,1,0")
+        "v_mul_f32_dpp %0, %4, %5" STAC_DPP("0,0,0,0")
+        "v_fmac_f32_dpp %0, %4, %1" STAC_DPP("1,1,1,1")
+        "v_fmac_f32_dpp %0, %4, %2" STAC_DPP("2,2,2,2")
+        "v_fmac_f32_dpp %0, %4, %3 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(r), "=&v"(R1), "=&v"(R2), "=&v"(R3)
+        : "v"(qc), "v"(ql), "v"(L.m1), "v"(L.m2), "v"(L.m3));
+    return r;
+}
+// Steps [t, end) of a pass without a restart: the next flagged step at or behind `from`, or n
+__device__ __forceinline__ int fk3_seg_end(const uint32_t mask, const int from, const int n) {
+    const uint32_t rest = from < 32 ? (mask >> from) << from : 0u;
+    return rest ? min(__builtin_ctz(rest), n) : n;
+}
+// P1.  T1: rows of four records {ql word of the NEXT step, out word, restart word | -1, -}; row 0 is the prologue, row t + 1 step t.
+// mask bit t: some position restarts in step t (then every position runs the select; the others keep their value).
+__device__ __forceinline__ void fk3_p1(const float *T1, const int n1, const uint32_t mask, float *CBc, const Fk3Lane &L) {
+    const float *rp = T1 + 4 * L.pp;
+    float ql = CBc[__builtin_bit_cast(int, rp[0]) + L.c];
+    rp += 16;
+    int4 rec = lds4i(rp);
+    float qc = 0.0f;
+    for (int t = 0; t < n1;) {
+        if ((mask >> t) & 1u) {
+            const float rl = CBc[(rec.z >= 0 ? rec.z : rec.y) + L.c];
+            qc = rec.z >= 0 ? rl : qc;
+        }
+        const int te = fk3_seg_end(mask, t + 1, n1);
+        // two steps per trip, the records in turn in `rec` and `rec2`: nothing is copied from one step to the next
+        for (; t + 2 <= te; t += 2) {
+            const int4 rec2 = lds4i(rp + 16);
+            const float ql2 = CBc[rec.x + L.c];
+            const float q1 = fk3_qmul(qc, ql, L);
+            CBc[rec.y + L.c] = q1;
+            rp += 32;
+            rec = lds4i(rp);
+            ql = CBc[rec2.x + L.c];
+            qc = fk3_qmul(q1, ql2, L);
+            CBc[rec2.y + L.c] = qc;
+        }
+        if (t < te) {
+            rp += 16;
+            const int4 nrec = lds4i(rp);
+            const float nql = CBc[rec.x + L.c];
+            qc = fk3_qmul(qc, ql, L);
+            CBc[rec.y + L.c] = qc;
+            rec = nrec;
+            ql = nql;
+            ++t;
+        }
+    }
+}
+// P2.  T2: tasks {v.x, v.y, v.z, quaternion word | result word << 16}, n2 a multiple of the group width (no-op tasks at the end).
+__device__ __forceinline__ void fk3_p2(const float *T2, const int n2, float *CBc, const int lf, const int gf) {
+    for (int i0 = 0; i0 < n2; i0 += gf) {  // (whole rounds: no lane-dependent trip count)
+        const float4 tk = lds4(T2 + 4 * (i0 + lf));
+        const int w = __builtin_bit_cast(int, tk.w);
+        const float4 q4 = lds4(CBc + (w & 0xFFFF));  // (w, x, y, z)
+        const V3 r = rotate(V3{tk.x, tk.y, tk.z}, Q4{q4.x, q4.y, q4.z, q4.w});
+        float *o = CBc + (int)((unsigned)w >> 16);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    }
+}
+// P3.  The slot of (step t, position pp) is pb + 3 * (4 t + pp); T3[4 t + pp] = restart word | -1.
+__device__ __forceinline__ void fk3_p3(const int *T3, const int n3, const uint32_t mask, float *CBc, const int pb, const Fk3Lane &L) {
+    const int cc = L.c ? L.c - 1 : 0;  // (lane 0 of a quad doubles lane 1: the same loads, the same values stored to the same words)
+    float *slot = CBc + pb + 3 * L.pp + cc;
+    const int *rp = T3 + L.pp;
+    float v = slot[0];
+    float p = 0.0f;
+    for (int t = 0; t < n3;) {
+        if ((mask >> t) & 1u) {
+            const int rs = rp[4 * t];
+            const float rl = CBc[(rs >= 0 ? rs : pb) + cc];
+            p = rs >= 0 ? rl : p;
+        }
+        const int te = fk3_seg_end(mask, t + 1, n3);
+#pragma unroll 4
+        for (; t < te; ++t) {
+            const float nv = slot[12];  // (slack behind the last step's slots: the root position, the sink, one more)
+            p = p + v;
+            slot[0] = p;
+            slot += 12;
+            v = nv;
+        }
+    }
+}
+struct Fk3Prog { const float *T1, *T2; const int *T3, *site; int n1, n2, n3; uint32_t m1, m3; };
+// all three passes; lf = lane in the group of gf lanes (16 or 32; the first 16 run P1 and P3)
+__device__ __forceinline__ void fk3_run(const Fk3Prog &G3, float *CBc, const int pb, const int lf, const int gf) {
+    const Fk3Lane L = fk3_lane(lf & 15);
+    if (gf == 16 || lf < 16) fk3_p1(G3.T1, G3.n1, G3.m1, CBc, L);
+    wave_sync();
+    fk3_p2(G3.T2, G3.n2, CBc, lf, gf);
+    wave_sync();
+    if (gf == 16 || lf < 16) fk3_p3(G3.T3, G3.n3, G3.m3, CBc, pb, L);
+    wave_sync();
 }
 
 }  // namespace stac

@@ -224,8 +224,8 @@ void q_phase_kernel(const QArgs a_in) {
 #define CAND(r, e) clipf(FMA(-eta, g[r], y[r]), LB(r, e), UB(r, e))
     const float eps = 1.1920929e-7f;
 
-    // bx[0] = world
-    if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
+    // bx[0] = world (the lean kernels' split kinematics have no world entry)
+    if (!LEAN && lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
 
     // initial qpos, keypoints of frame 0, first solve
     size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
@@ -404,6 +404,8 @@ void q_phase_kernel(const QArgs a_in) {
         float *const sw = CB + H.c_sw, *const gg = sw, *const r2 = CB + H.c_r2;
         float *const qe = sw, *const kpl = CB + H.c_kp;
         const TripCtx cx{lg, nq, K, kpl, lbv, ubv, P + H.off_qpos0};
+        // lean kernels (split kinematics, PlanHeader::fk3): word of the root position inside a chain's region (behind the slots of P3)
+        const int root_w = LEAN ? H.c3_pb + 12 * H.fk3_cap3 : 0;
         if (!SPEC && a.ctl && !a.resume) {
             // hand-off: a chain about to start an iteration after most chains of the launch are done goes to the
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
@@ -484,7 +486,8 @@ void q_phase_kernel(const QArgs a_in) {
         // root passes weigh the trunk keypoints only: when every live chain of the wave is in one, the kinematics stop at
         // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)
         const bool root_pass = !a.single && kind < 2;
-        const int n_ml_root = (a.n_mlev_root > 0 && !__any(live_in && !root_pass)) ? a.n_mlev_root : 0;
+        const int n_mlev_root_a = LEAN ? a.fk3r_n3 : a.n_mlev_root;  // (lean: the pruned split-kinematics program, if the call has one)
+        const int n_ml_root = (n_mlev_root_a > 0 && !__any(live_in && !root_pass)) ? n_mlev_root_a : 0;
         // root fast trip: only the root coordinates are staged and only the root joint's local transform is refreshed
         // (lite) once the other joints' local quaternions sit untouched in their ja entries
         const bool fast_trip = !SPEC && a.root_fast > 0 && n_ml_root > 0;
@@ -503,7 +506,7 @@ void q_phase_kernel(const QArgs a_in) {
         const bool lite = fast_trip && !__any(live_in && !ql_fresh);
 
         // the world entry of the transform array (the gradient pass of the previous trip left its range sums there)
-        if (lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
+        if (!LEAN && lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
         // ---- make_qs (utils.py:129-144): qf = (1 - mask) * q0 + mask * point ---------------------
         // A free joint at qpos 0 .. 6 (active joint 0: QArgs::free0p): its pre-pass out of the registers of lanes 0 .. 6, which
         // hold the staged coordinates v.  Every lane fetches the four raw quaternion components from lanes 3 .. 6 (one
@@ -524,7 +527,8 @@ void q_phase_kernel(const QArgs a_in) {
                 const float val = lg < 3 ? v : qn;
                 float *const sink = CB + H.c_sink;
                 float *d_qe = lg < 7 ? qe + lg : sink;
-                float *d_ja = lg < 3 ? ja + lg : (lg < 7 ? ja + kXq + (c == 0 ? 3 : c - 1) : sink + 1);
+                // (split kinematics: the root position slot of P3 and entry 0 of the quaternion array, which holds (w, x, y, z))
+                float *d_ja = lg < 3 ? CB + root_w + lg : (lg < 7 ? CB + H.c3_qb + c : sink + 1);
                 float *d_qs = (lg >= 3 && lg < 7) ? qsv + 4 * qord + c : sink + 2;
                 float *d_jn = lg == 3 ? jn + qord : sink + 3;
                 *d_qe = val;
@@ -593,20 +597,52 @@ void q_phase_kernel(const QArgs a_in) {
         PROF_TICK(1);  // stage
 
         if (!(lite && a.free0p)) {  // (a root fast trip on a free root has nothing else to prepare)
-            joint_local_prepass<LEAN>(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0, (a.flags & 16) != 0 && j0 == 1);
+            if constexpr (LEAN) {
+                // every hinge's joint-local quaternion (w, x, y, z) into its own array: a pruned trip keeps what it does not use
+                for (int j = lg + 1; j < H.naj; j += G) {
+                    const float *jr = jrec + 12 * j;
+                    const int ad = reinterpret_cast<const int *>(jr)[1];
+                    const float4 jp4 = lds4(jr + 4);  // pos, q0
+                    const float4 ja4 = lds4(jr + 8);  // axis, range id
+                    const float angle = qe[ad] - jp4.w;
+                    float sn, cs;
+                    sincos_(angle * 0.5f, &sn, &cs);
+                    *reinterpret_cast<float4 *>(CB + H.c3_ql + 4 * j) = float4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn};
+                }
+            } else {
+                joint_local_prepass<LEAN>(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0, (a.flags & 16) != 0 && j0 == 1);
+            }
             wave_sync();
         }
         PROF_TICK(10);  // joint-local pre-pass
 
         // ---- forward kinematics, level by level (mjx smooth.kinematics) -------------
-        fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root, a.n_run_root);
+        const int *site3 = nullptr;  // lean: per site, the words of its body's position and quaternion under the program that ran
+        if constexpr (LEAN) {
+            const bool rootp = n_ml_root > 0;
+            const float *pg = P + (rootp ? H.off3_root : H.off3_prog);
+            Fk3Prog G3;
+            G3.T1 = pg;
+            G3.T2 = pg + 16 * (H.fk3_cap1 + 2);
+            G3.T3 = reinterpret_cast<const int *>(G3.T2 + 4 * H.fk3_cap2);
+            G3.site = G3.T3 + 4 * H.fk3_cap3;
+            G3.n1 = rootp ? a.fk3r_n1 : H.fk3_n1;
+            G3.n2 = rootp ? a.fk3r_n2 : H.fk3_n2;
+            G3.n3 = rootp ? a.fk3r_n3 : H.fk3_n3;
+            G3.m1 = (uint32_t)(rootp ? a.fk3r_m1 : H.fk3_m1);
+            G3.m3 = (uint32_t)(rootp ? a.fk3r_m3 : H.fk3_m3);
+            site3 = G3.site;
+            fk3_run(G3, CB, H.c3_pb, lg, G);
+        } else {
+            fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root, a.n_run_root);
+        }
         // after a root fast trip the local quaternions are still where the pre-pass put them (sunk ja stores); after any
         // other trip the pre-joint quaternions have replaced them
         ql_fresh = fast_trip && tail_ok;  // (a chain whose other coordinates leave the box never takes the lite path)
 
         PROF_TICK(2);  // FK
         // ---- marker sites: residual, per-site loss term, per-site wrench ----------------------------
-        const V3 cref = ld_tpos(bx + kXf);  // entry 1 = first active body (the root): moments are taken about it
+        const V3 cref = LEAN ? ld3(CB + root_w) : ld_tpos(bx + kXf);  // entry 1 = first active body (the root): moments are taken about it
         const bool trunk_w = (!a.single) && kind < 2;
         const int Kpad = (K + 3) & ~3;
         // one site: world position, weighted residual against the keypoint (kx, ky, kz), loss term; the wrench
@@ -614,8 +650,19 @@ void q_phase_kernel(const QArgs a_in) {
         auto site_term = [&](const int k, const float kx, const float ky, const float kz, const bool tw) -> float {
             const float4 sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
-            const float *bp = bx + (ss & 0xFFFF) * kXf;
-            const V3 sx = add3(ld_tpos(bp), rotate(V3{sr.x, sr.y, sr.z}, ld_tquat(bp)));
+            V3 bpos_w;
+            Q4 bquat_w;
+            if constexpr (LEAN) {
+                const int s3 = site3[k];
+                bpos_w = ld3(CB + (s3 & 0xFFFF));
+                const float4 q4 = lds4(CB + (int)((unsigned)s3 >> 16));
+                bquat_w = Q4{q4.x, q4.y, q4.z, q4.w};
+            } else {
+                const float *bp = bx + (ss & 0xFFFF) * kXf;
+                bpos_w = ld_tpos(bp);
+                bquat_w = ld_tquat(bp);
+            }
+            const V3 sx = add3(bpos_w, rotate(V3{sr.x, sr.y, sr.z}, bquat_w));
             float w0, w1, w2;
             if (a.single) {
                 w0 = a.kpw3[3 * k] ? 1.f : 0.f; w1 = a.kpw3[3 * k + 1] ? 1.f : 0.f; w2 = a.kpw3[3 * k + 2] ? 1.f : 0.f;
@@ -764,8 +811,17 @@ void q_phase_kernel(const QArgs a_in) {
             const float4 ja4 = lds4(jr + 8);  // axis, range id
             const float *rw = CBx + H.c_rw + kXf * __builtin_bit_cast(int, ja4.w);
             const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
-                const V3 anchor = ld_tpos(jax_ + kXf * j);
-                const Q4 prequat = ld_tquat(jax_ + kXf * j);
+                V3 anchor;
+                Q4 prequat;
+                if constexpr (LEAN) {  // (split kinematics: where the joint's anchor and its pre-joint quaternion are, from the full program's joint words)
+                    const int jw = reinterpret_cast<const int *>(P + H.off3_site)[K + j];
+                    anchor = ld3(CBx + (jw & 0xFFFF));
+                    const float4 q4 = lds4(CBx + (int)((unsigned)jw >> 16));
+                    prequat = Q4{q4.x, q4.y, q4.z, q4.w};
+                } else {
+                    anchor = ld_tpos(jax_ + kXf * j);
+                    prequat = ld_tquat(jax_ + kXf * j);
+                }
                 const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
                 // (lean kernels know the types: joint 0 is the free root, every other one a hinge)
                 const bool is_hinge = LEAN_HINGES ? true : (LEAN ? j != 0 : ty == JHINGE);
@@ -797,10 +853,9 @@ void q_phase_kernel(const QArgs a_in) {
         // The gradient of a free joint at qpos 0 .. 6 (active joint 0; QArgs::root_free / free0p), component lg on lane lg
         // < 7: the formulas of joint_gradient's free branch -- same operations, same order per component -- but the four
         // divisions side by side instead of one lane doing all seven components while the others wait.
-        auto free0_gradient = [&](float *CBx, const V3 crefx, const int rid, const int qord) -> float {
-            const float *rw = CBx + H.c_rw + kXf * rid;
+        auto free0_gradient = [&](float *CBx, const V3 crefx, const float *rw, const int qord) -> float {
             const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
-            const V3 anchor = ld_tpos(CBx + H.c_ja);
+            const V3 anchor = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_ja);
             const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
             const Q4 qh = ld4(CBx + H.c_qsv + 4 * qord);
             const V3 u = {qh.x, qh.y, qh.z};
@@ -828,12 +883,12 @@ void q_phase_kernel(const QArgs a_in) {
                 float acc = 0.f;
                 for (uint32_t m = a.root_trunk_lo; m; m &= m - 1) acc = acc + src[kXf * __builtin_ctz(m)];
                 for (uint32_t m = a.root_trunk_hi; m; m &= m - 1) acc = acc + src[kXf * (32 + __builtin_ctz(m))];
-                CB[H.c_rw + kXf * rid0 + co] = acc;
+                CB[(LEAN ? H.c3_rw0 : H.c_rw + kXf * rid0) + co] = acc;  // (lean: beside the joint-local quaternions, which a fast trip keeps)
             }
             wave_sync();
             PROF_TICK(5);  // range sums
             if (a.free0p) {
-                const float gv = free0_gradient(CB, cref, rid0, a.free0p - 1);
+                const float gv = free0_gradient(CB, cref, CB + (LEAN ? H.c3_rw0 : H.c_rw + kXf * rid0), a.free0p - 1);
                 if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
             } else {
                 for (int j = lg; j < a.n_root_joints; j += G) joint_gradient(j, CB, cref, gg);
@@ -883,7 +938,7 @@ void q_phase_kernel(const QArgs a_in) {
                 }
             }
             if (a.free0p) {  // the free root joint: one component per lane, its four divisions side by side
-                const float gv = free0_gradient(CB, cref, __builtin_bit_cast(int, jrec[11]), a.free0p - 1);
+                const float gv = free0_gradient(CB, cref, CB + H.c_rw + kXf * __builtin_bit_cast(int, jrec[11]), a.free0p - 1);
                 if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
             }
             wave_sync();
@@ -1081,7 +1136,7 @@ void q_phase_kernel(const QArgs a_in) {
                 float *CBa = CBw + cs * H.chain_stride, *CBn = CBw + (NC + cs) * H.chain_stride;
                 if constexpr (NW == 1) {  // the LC lanes of this wavefront that work on the chain share both gradient passes
                     const int ll = lane % LC;
-                    const V3 crefa = ld_tpos(CBa + H.c_bx + kXf), crefn = ld_tpos(CBn + H.c_bx + kXf);
+                    const V3 crefa = LEAN ? ld3(CBa + root_w) : ld_tpos(CBa + H.c_bx + kXf), crefn = LEAN ? ld3(CBn + root_w) : ld_tpos(CBn + H.c_bx + kXf);
                     for (int e = ll; e < nqpad; e += LC) { gxa[e] = 0.0f; gxn[e] = 0.0f; }
                     for (int i = ll; i < 2 * H.nrange; i += LC) {
                         const bool nx = i >= H.nrange;
@@ -1102,7 +1157,7 @@ void q_phase_kernel(const QArgs a_in) {
                     if (mine || help) {
                         const bool first = mine ? wa == wave : wa == (wave ^ 1);
                         float *gx = first ? gxa : gxn, *CBx = first ? CBa : CBn;
-                        const V3 crefx = ld_tpos(CBx + H.c_bx + kXf);
+                        const V3 crefx = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_bx + kXf);
                         if (mine) { for (int t = 6 + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
                         else if (lane < 6) range_task(lane, CBx);
                         wave_sync();
@@ -1632,17 +1687,38 @@ bool q_phase_has_variant(int G, int nq, int wpe) {
     return false;
 }
 
+// Is there a lean instantiation (SPECP bit 0) for this shape?  spec = 0: throughput kernel with register cap wpe; else the latency
+// kernel with `spec` roles of G lanes.
+bool q_phase_has_lean_variant(int G, int nq, int wpe, int spec) {
+    if (spec) {
+#define STAC_HAS(GG, RR, NRR) if (G == GG && spec == NRR && nq <= GG * RR) return true;
+        STAC_Q_SPEC_LEAN_SHAPES(STAC_HAS)
+#undef STAC_HAS
+        return false;
+    }
+#define STAC_HAS(GG, RR, WW) if (G == GG && wpe == WW && nq <= GG * RR) return true;
+    STAC_Q_LEAN_SHAPES(STAC_HAS)
+#undef STAC_HAS
+    return false;
+}
+// The launch-wide choices the lean kernels have compiled in (q_phase_kernel, SPECP bit 0): phase mode with the model's own box, only
+// hinges below a free root at qpos 0 .. 6 (QArgs::flags == 16: set_hinges_flag, no developer flag), the split kinematics
+// (PlanHeader::fk3: stac_plan.hpp), every site in registers at this group width.  The host decides with it which chain layout
+// the launch gets (run_q) and passes its decision to launch_q_phase.
+bool q_phase_lean_conditions(const QArgs &a, int G) {
+    return !a.single && !a.bounds && a.flags == 16 && a.free0p == 1 && a.h.fk3 == 1 && a.h.K <= lean_site_rounds(G) * G && a.h.nqj == 1 &&
+           !a.h.has_ball && G >= 16;
+}
+
 // wpb = wavefronts per workgroup (they share the plan copy), wpe = register-cap variant (2, 3 or 4 wavefronts per SIMD; the
 // nearest one that exists for G is taken), spec = evaluation roles per chain in latency mode (0 = throughput mode).
+// lean: the launch carries the lean chain layout (the host has checked q_phase_lean_conditions and that the shape exists).
 // *capacity_out = G * NQR of the instantiation that ran, 0 if none holds nq at this G.
 hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
-                          int *capacity_out) {
+                          int *capacity_out, bool lean) {
     const int nq = a.h.nq;
     *capacity_out = 0;
-    // the lean kernels (q_phase_kernel, SPECP bit 0) where their compile-time choices are this launch's
-    // (nqj == 1 and a uniform program: the free root is the only quaternion joint and no joint is a slide: all others are hinges)
-    const bool lean = !a.single && !a.bounds && a.flags == 16 /* only hinges below the root (set_hinges_flag), no developer flag */ && a.free0p == 1 && a.h.fk_uniform && a.h.fk_rec_words == 12 &&
-                      4 * a.h.max_width <= G && a.h.K <= lean_site_rounds(G) * G && a.h.nqj == 1 && !a.h.has_ball;
+    if (lean && !(q_phase_lean_conditions(a, G) && q_phase_has_lean_variant(G, nq, wpe, spec))) return hipErrorInvalidValue;
     if (spec) {
 #define STAC_TRY_SPEC_LEAN(GG, RR, NRR)                             \
     if (lean && G == GG && spec == NRR && nq <= GG * RR) {          \
@@ -1660,7 +1736,7 @@ hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, siz
 #undef STAC_TRY_SPEC
         return hipErrorInvalidValue;
     }
-    if (!q_phase_has_variant(G, nq, wpe)) wpe = 2;  // (every G has its 2-per-SIMD variants)
+    if (!lean && !q_phase_has_variant(G, nq, wpe)) wpe = 2;  // (every G has its 2-per-SIMD variants)
 #define STAC_TRY_LEAN(GG, RR, WW)                                   \
     if (lean && G == GG && wpe == WW && nq <= GG * RR) {            \
         *capacity_out = GG * RR;                                    \
