@@ -19,9 +19,11 @@ HEADERS = [CSRC / "stac_plan.hpp", CSRC / "stac_device.hpp", CSRC.parents[1] / "
 # shape whose results depended on what the previous launch left in registers / scratch): with it off that shape is correct under
 # every poison pattern, with it on it is wrong on 36 of 36 models (profiles/r04/stale_spill_repro.txt, reproducer:
 # tests/tools/repro_stale_spill/).  Costs nothing on the throughput bench, 2 % on 250-frame clips.
-# -amdgpu-sched-strategy=max-memory-clause: LDS reads grouped ahead of their uses, +1.5 ... 2 % (profiles/r03/flag_sweep.txt).
+# -amdgpu-sched-strategy=max-ilp: with the split kinematics (round 5) the kernels wait on dependent instructions more than on LDS reads
+# (dependent VALU instructions of a wavefront do not overlap: profiles/r04/valu_issue_micro.txt): +3 % on the 10 000-frame bench, +4.6 % on
+# 250-frame clips over max-memory-clause, which rounds 3-4 used (profiles/r05/NOTES.md).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-fno-slp-vectorize",
-         "-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-mllvm", "-amdgpu-opt-vgpr-liverange=false"]
+         "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-opt-vgpr-liverange=false"]
 FLAGS += os.environ.get("STAC_HIP_EXTRA_FLAGS", "").split()
 
 
