@@ -1019,15 +1019,32 @@ __device__ __forceinline__ void fk3_p1(const float *T1, const int n1, const uint
         }
     }
 }
-// P2.  T2: tasks {v.x, v.y, v.z, quaternion word | result word << 16}, n2 a multiple of the group width (no-op tasks at the end).
+// P2.  T2: tasks {v.x, v.y, v.z, quaternion word | result word << 16}, n2 a multiple of 32 (no-op tasks at the end).  PAIR (throughput
+// kernels at 16 lanes): two rounds of lanes at once -- their loads in flight together, their arithmetic, chains of dependent
+// instructions, interleaved (a lone wavefront of the latency kernels pays per instruction, dependent or not: one round at a time).
+template <bool PAIR>
 __device__ __forceinline__ void fk3_p2(const float *T2, const int n2, float *CBc, const int lf, const int gf) {
-    for (int i0 = 0; i0 < n2; i0 += gf) {  // (whole rounds: no lane-dependent trip count)
-        const float4 tk = lds4(T2 + 4 * (i0 + lf));
-        const int w = __builtin_bit_cast(int, tk.w);
-        const float4 q4 = lds4(CBc + (w & 0xFFFF));  // (w, x, y, z)
-        const V3 r = rotate(V3{tk.x, tk.y, tk.z}, Q4{q4.x, q4.y, q4.z, q4.w});
-        float *o = CBc + (int)((unsigned)w >> 16);
-        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    if constexpr (PAIR) {
+        for (int i0 = 0; i0 < n2; i0 += 2 * gf) {  // (whole rounds: no lane-dependent trip count; 2 gf = 32 divides n2)
+            const float4 ta = lds4(T2 + 4 * (i0 + lf));
+            const float4 tb = lds4(T2 + 4 * (i0 + gf + lf));
+            const int wa = __builtin_bit_cast(int, ta.w), wb = __builtin_bit_cast(int, tb.w);
+            const float4 qa = lds4(CBc + (wa & 0xFFFF)), qb = lds4(CBc + (wb & 0xFFFF));  // (w, x, y, z)
+            const V3 ra = rotate(V3{ta.x, ta.y, ta.z}, Q4{qa.x, qa.y, qa.z, qa.w});
+            const V3 rb = rotate(V3{tb.x, tb.y, tb.z}, Q4{qb.x, qb.y, qb.z, qb.w});
+            float *oa = CBc + (int)((unsigned)wa >> 16), *ob = CBc + (int)((unsigned)wb >> 16);
+            oa[0] = ra.x; oa[1] = ra.y; oa[2] = ra.z;
+            ob[0] = rb.x; ob[1] = rb.y; ob[2] = rb.z;
+        }
+    } else {
+        for (int i0 = 0; i0 < n2; i0 += gf) {
+            const float4 tk = lds4(T2 + 4 * (i0 + lf));
+            const int w = __builtin_bit_cast(int, tk.w);
+            const float4 q4 = lds4(CBc + (w & 0xFFFF));  // (w, x, y, z)
+            const V3 r = rotate(V3{tk.x, tk.y, tk.z}, Q4{q4.x, q4.y, q4.z, q4.w});
+            float *o = CBc + (int)((unsigned)w >> 16);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        }
     }
 }
 // P3.  The slot of (step t, position pp) is pb + 3 * (4 t + pp); T3[4 t + pp] = restart word | -1.
@@ -1055,12 +1072,13 @@ __device__ __forceinline__ void fk3_p3(const int *T3, const int n3, const uint32
     }
 }
 struct Fk3Prog { const float *T1, *T2; const int *T3, *site; int n1, n2, n3; uint32_t m1, m3; };
-// all three passes; lf = lane in the group of gf lanes (16 or 32; the first 16 run P1 and P3)
+// all three passes; lf = lane in the group of gf lanes (16 or 32; the first 16 run P1 and P3); THROUGHPUT: not a latency kernel
+template <bool THROUGHPUT>
 __device__ __forceinline__ void fk3_run(const Fk3Prog &G3, float *CBc, const int pb, const int lf, const int gf) {
     const Fk3Lane L = fk3_lane(lf & 15);
     if (gf == 16 || lf < 16) fk3_p1(G3.T1, G3.n1, G3.m1, CBc, L);
     wave_sync();
-    fk3_p2(G3.T2, G3.n2, CBc, lf, gf);
+    fk3_p2<THROUGHPUT>(G3.T2, G3.n2, CBc, lf, gf);
     wave_sync();
     if (gf == 16 || lf < 16) fk3_p3(G3.T3, G3.n3, G3.m3, CBc, pb, L);
     wave_sync();

@@ -599,15 +599,24 @@ void q_phase_kernel(const QArgs a_in) {
         if (!(lite && a.free0p)) {  // (a root fast trip on a free root has nothing else to prepare)
             if constexpr (LEAN) {
                 // every hinge's joint-local quaternion (w, x, y, z) into its own array: a pruned trip keeps what it does not use
-                for (int j = lg + 1; j < H.naj; j += G) {
-                    const float *jr = jrec + 12 * j;
-                    const int ad = reinterpret_cast<const int *>(jr)[1];
-                    const float4 jp4 = lds4(jr + 4);  // pos, q0
-                    const float4 ja4 = lds4(jr + 8);  // axis, range id
-                    const float angle = qe[ad] - jp4.w;
-                    float sn, cs;
-                    sincos_(angle * 0.5f, &sn, &cs);
-                    *reinterpret_cast<float4 *>(CB + H.c3_ql + 4 * j) = float4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn};
+                // Three rounds of lanes at once (the rodent's 38 hinges on 16 lanes: all of them): the rounds are independent chains of
+                // dependent instructions, which the scheduler interleaves.  A lane whose round has no joint left takes the last
+                // joint again: the same value to the same words.
+                // (throughput kernels: a lone wavefront of the latency kernels pays per instruction, dependent or not)
+                constexpr int U = SPEC != 0 ? 1 : (G == 16 ? 3 : 2);
+                for (int j0 = lg + 1; j0 < H.naj; j0 += U * G) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int j = min(j0 + u * G, H.naj - 1);
+                        const float *jr = jrec + 12 * j;
+                        const int ad = reinterpret_cast<const int *>(jr)[1];
+                        const float4 jp4 = lds4(jr + 4);  // pos, q0
+                        const float4 ja4 = lds4(jr + 8);  // axis, range id
+                        const float angle = qe[ad] - jp4.w;
+                        float sn, cs;
+                        sincos_(angle * 0.5f, &sn, &cs);
+                        *reinterpret_cast<float4 *>(CB + H.c3_ql + 4 * j) = float4{cs, ja4.x * sn, ja4.y * sn, ja4.z * sn};
+                    }
                 }
             } else {
                 joint_local_prepass<LEAN>(H, P, CB, lg, G, lite ? a.n_root_joints : H.naj, j0, (a.flags & 16) != 0 && j0 == 1);
@@ -632,7 +641,7 @@ void q_phase_kernel(const QArgs a_in) {
             G3.m1 = (uint32_t)(rootp ? a.fk3r_m1 : H.fk3_m1);
             G3.m3 = (uint32_t)(rootp ? a.fk3r_m3 : H.fk3_m3);
             site3 = G3.site;
-            fk3_run(G3, CB, H.c3_pb, lg, G);
+            fk3_run<(SPEC == 0 && G == 16)>(G3, CB, H.c3_pb, lg, G);
         } else {
             fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root, a.n_run_root);
         }
@@ -923,7 +932,16 @@ void q_phase_kernel(const QArgs a_in) {
                     gg[ad] = dot3(rotate(V3{ja4.x, ja4.y, ja4.z}, prequat), tau);
                 }
             } else {
-                for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
+                if constexpr (LEAN && SPEC == 0) {
+                    // three rounds of lanes at once, as in the pre-pass (a lane without a joint left repeats the last one)
+                    constexpr int U = G == 16 ? 3 : 2;
+                    for (int jb = lg + j0; jb < naj_g; jb += U * G) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) joint_gradient(min(jb + u * G, naj_g - 1), CB, cref, gg);
+                    }
+                } else {
+                    for (int j = lg + j0; j < naj_g; j += G) joint_gradient(j, CB, cref, gg);
+                }
             }
             wave_sync();
             const uint32_t abits = SPEC ? mbits : (MB[nkinds * G + lg] & mbits);  // optimised coordinates that HAVE a gradient entry
