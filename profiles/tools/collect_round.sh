@@ -37,6 +37,7 @@ done
   run "fit mode, 1000 frames as 100 clips" --mode fit --frames 1000 --frames-per-clip 10 --steps 3 --warmup 1
   run "fit mode, one chain of 1000 frames (reference sequencing, config 3)" --mode fit --frames 1000 --frames-per-clip 1000 --steps 1 --warmup 0
   run "run mode: Stac.ik_only end to end, 100k frames at 250 per clip, all outputs + result file" --mode run --frames 100000 --frames-per-clip 250 --steps 2 --warmup 1
+  run "strong scaling, N = 1 point: BASELINE configs[3], 1 M frames as 4000 clips of 250 on one GPU" --scaling strong --frames 1000000 --frames-per-clip 250 --steps 1 --warmup 1
   echo "]"
 } > $OUT/secondary.json
 # the FK output pass on its own: rocprofv3 kernel stats of a run-mode bench (fk_kernel's line: duration against 2 744 B per pose)
