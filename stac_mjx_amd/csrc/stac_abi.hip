@@ -926,7 +926,7 @@ static bool lat_one_wave_ok(const PlanHeader &h) { return h.nq <= 16 * 8; }
 static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nchains = -1, int nr = 8) {
     constexpr size_t kGranule = 1280;
     SpecShape best{G, 0, 0, 0};
-    if (G == 8 || G == 16) {  // 256-VGPR kernel: two waves per SIMD, eight per CU; 64 / (G nr) chains per wavefront
+    if ((G == 8 || G == 16) && G * nr <= 64) {  // 256-VGPR kernel: two waves per SIMD, eight per CU; 64 / (G nr) chains per wavefront
         const int cw = 64 / (G * nr);
         for (int w = 1; w <= 8; ++w) {
             size_t lds = spec_lds_bytes(h, G, nkinds, w * cw, nr);
@@ -939,7 +939,7 @@ static SpecShape pick_spec_shape(const PlanHeader &h, int G, int nkinds, long nc
         }
         return best;
     }
-    const int nw = G / 8;  // 256-VGPR kernels as well (the 128-VGPR builds spill > 100 registers): eight waves per CU
+    const int nw = G * nr / 64;  // wavefronts per chain; 256-VGPR kernels as well (the 128-VGPR builds spill > 100 registers): eight waves per CU
     size_t lds = spec_lds_bytes(h, G, nkinds, 1);
     if (lds > kLdsPerCu) return best;
     lds = (lds + kGranule - 1) / kGranule * kGranule;
@@ -1189,6 +1189,14 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         if (sg == 16) sr = 4;  // four roles of 16 lanes: one chain per wavefront
         a.free0p = free0_ordinal_p1(m, sg);
         set_hinges_flag(m, a);
+        // Between the four-wavefront kernel's resident chains (512) and twice that: TWO wavefronts per chain, eight roles of 16 lanes
+        // (lean kernel only) -- one trip per iteration like the four-wavefront kernel instead of 1.16 longer ones (measured, 1 000 chains
+        // of 250 frames: profiles/r05/NOTES.md)
+        if (sg == 16 && dbg.specg < 0 && lean_for(a, 16, 8, true)) {
+            const SpecShape s2 = pick_spec_shape(lean_header(a), 16, nkinds, -1, 8);
+            if (s2.resident && (long)nchains <= s2.resident) sr = 8;
+        }
+        if (sg == 16 && dbg.specr == 8 && lean_for(a, 16, 8, true)) sr = 8;
         const bool lean = lean_for(a, sg, sr, true);
         const PlanHeader hh = lean ? lean_header(a) : m->h;
         const SpecShape sh = pick_spec_shape(hh, sg, nkinds, nchains, sr);

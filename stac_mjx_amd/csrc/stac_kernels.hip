@@ -65,7 +65,7 @@ void q_phase_kernel(const QArgs a_in) {
     constexpr int SPEC = SPECP & ~1;
     constexpr bool LEAN = (SPECP & 1) != 0;
     const QArgs &a = a_in;
-    static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 32 || G == 64)) || (SPEC == 4 && (G == 8 || G == 16)), "speculative mode: 8 (or 4) roles of G lanes");
+    static_assert(SPEC == 0 || (SPEC == 8 && (G == 8 || G == 16 || G == 32 || G == 64)) || (SPEC == 4 && (G == 8 || G == 16)), "speculative mode: 8 (or 4) roles of G lanes");
     extern __shared__ float lds[];
     constexpr int CPW = 64 / G;
     constexpr int NR = SPEC ? SPEC : 1, NC = SPEC ? SPEC / 2 : 1;  // roles per chain, of which candidates
@@ -1170,18 +1170,21 @@ void q_phase_kernel(const QArgs a_in) {
                     // read them, its neighbour (wave ^ 1: a wave of the same half of the roles) the longest range -- all
                     // sites, for the root -- and the joints on it (the free joint's formulas are the long ones).  No range or
                     // gradient entry is shared between the two, so they only meet at the barrier that follows anyway.
+                    // (TWO wavefronts per chain -- eight roles of 16 lanes --: wave 0 holds the candidates, wave 1 the momentum points,
+                    //  each runs the whole gradient pass of its one evaluation)
+                    constexpr bool SOLO = NW == 2;
                     const int wa = cs / CPW, wn = (NC + cs) / CPW;  // wave-uniform
-                    const bool mine = wa == wave || wn == wave, help = wa == (wave ^ 1) || wn == (wave ^ 1);
+                    const bool mine = wa == wave || wn == wave, help = !SOLO && (wa == (wave ^ 1) || wn == (wave ^ 1));
                     if (mine || help) {
                         const bool first = mine ? wa == wave : wa == (wave ^ 1);
                         float *gx = first ? gxa : gxn, *CBx = first ? CBa : CBn;
                         const V3 crefx = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_bx + kXf);
-                        if (mine) { for (int t = 6 + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
+                        if (mine) { for (int t = (SOLO ? 0 : 6) + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
                         else if (lane < 6) range_task(lane, CBx);
                         wave_sync();
                         for (int j = lane; j < H.naj; j += 64) {
                             const bool on_longest = __builtin_bit_cast(int, jrec[12 * j + 11]) == 0;
-                            if (on_longest != mine) joint_gradient(j, CBx, crefx, gx);
+                            if (SOLO || on_longest != mine) joint_gradient(j, CBx, crefx, gx);
                         }
                     }
                 }
@@ -1681,12 +1684,12 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 #ifdef STAC_INST_SUBSET  // developer builds (experiments): only the shapes of the default bench and of its 250-frame-clip leg
 #define STAC_Q_SHAPES(X) X(16, 5, 2) X(16, 5, 3)
 #define STAC_Q_LEAN_SHAPES(X) X(16, 5, 3)
-#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
+#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(16, 5, 8) X(32, 3, 8)
 #define STAC_Q_SPEC_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #else
 // lean kernels (SPECP bit 0): the shapes that rodent-sized models run in -- large batches, the straggler hand-off, few long clips
 #define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2)
-#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
+#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(16, 5, 8) X(32, 3, 8)
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
     X(16, 5, 2) X(16, 5, 3) X(16, 8, 2) X(16, 8, 3) X(16, 16, 2)                 \

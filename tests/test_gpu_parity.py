@@ -1073,6 +1073,7 @@ _SHAPE_CASES = [
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "8"}),         # q<8,10,2,8>
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),        # q<16,5,2,5>  (lean)
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),        # q<32,3,2,9>
+    ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16", "STAC_HIP_SPECR": "8"}),   # q<16,5,2,9>  (lean: two wavefronts per chain)
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16", "STAC_HIP_NOLEAN": "1"}),   # q<16,5,2,4>  (generic)
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32", "STAC_HIP_NOLEAN": "1"}),   # q<32,3,2,8>
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "64"}),        # q<64,2,2,8>
@@ -1121,6 +1122,36 @@ def test_default_launches_of_the_rodent_take_the_lean_kernels(rodent_setup, rode
     gen = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=6)
     gen.q_phase(rodent_mocap[300:312].reshape(4, 3, 69), **kw)
     assert _last_q_kernel(gen) == (32, 3, 2, 8)
+
+
+def test_split_kinematics_and_step_program_agree_bit_for_bit(rodent_setup, rodent_mocap, monkeypatch):
+    """Round 5: the lean kernels run the kinematics as three passes (quaternion chain, rotations, position chain:
+    PlanHeader::fk3) -- the same operations in the same order per result as the generic kernels' step program.  Every launch site
+    (throughput, latency with four wavefronts per chain, one-wavefront latency / hand-off) must give the generic kernels' bits
+    (STAC_HIP_NOFK3: no split-kinematics tables, hence no lean kernel), on root passes (pruned programs) and pose passes alike."""
+    from stac_mjx_amd.engine import Engine
+
+    fs = rodent_setup
+    kw = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=True)
+    cases = [("throughput + hand-off", np.tile(rodent_mocap[300:306], (800, 1)).reshape(4800, 1, 69), {}, (16, 5, 2, 5)),
+             ("latency, four wavefronts per chain", rodent_mocap[300:312].reshape(4, 3, 69), {}, (32, 3, 2, 9)),
+             ("throughput on request", rodent_mocap[300:340].reshape(20, 2, 69), dict(lanes_per_chain=16), None)]
+    lean = {}
+    for name, kp, ekw, shape in cases:
+        eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=8, **ekw)
+        lean[name] = eng.q_phase(kp, **kw)
+        got = _last_q_kernel(eng)
+        assert got[3] & 1, (name, got)  # a lean kernel ran
+        if shape is not None:
+            assert got == shape, (name, got)
+    monkeypatch.setenv("STAC_HIP_NOFK3", "1")
+    for name, kp, ekw, shape in cases:
+        eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-4, maxiter=8, **ekw)
+        ref = eng.q_phase(kp, **kw)
+        assert not (_last_q_kernel(eng)[3] & 1), name  # the generic kernel
+        for key in ("qpos", "frame_error", "counters"):
+            a, b = lean[name][key].cpu().numpy(), ref[key].cpu().numpy()
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (name, key)
 
 
 @pytest.mark.parametrize("model,lanes,solver,env", _SHAPE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else
