@@ -1066,7 +1066,7 @@ _SHAPE_CASES = [
     ("rodent", 16, "pg", {"STAC_HIP_WPE": "3", "STAC_HIP_NOLEAN": "1"}),        # q<16,5,3,0>
     ("rodent", 32, "pg", {"STAC_HIP_WPE": "2"}),                                # q<32,3,2,1>  (lean)
     ("rodent", 32, "pg", {"STAC_HIP_WPE": "2", "STAC_HIP_NOLEAN": "1"}),        # q<32,3,2,0>  (generic)
-    ("rodent", 32, "pg", {"STAC_HIP_WPE": "4"}),                                # q<32,3,4,0>
+    ("rodent", 32, "pg", {"STAC_HIP_WPE": "4", "STAC_HIP_NOLEAN": "1"}),        # q<32,3,4,0>  (generic only: a lean launch keeps its own variants)
     ("rodent", 64, "pg", {"STAC_HIP_WPE": "2"}),                                # q<64,2,2,0>
     ("rodent", 64, "pg", {"STAC_HIP_WPE": "4"}),                                # q<64,2,4,0>
     ("rodent", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "8", "STAC_HIP_SPECR": "4"}),   # q<8,10,2,4>
