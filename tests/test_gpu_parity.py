@@ -651,9 +651,11 @@ def test_lm_chain_queue_same_as_static_assignment(rodent_setup, rodent_mocap, mo
 
 
 # ---- random models: the plan builder (levels, positions, stored transforms, step program) on arbitrary trees ------------
-def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_bias=0.6):
+def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_bias=0.6, lean=False, k_max=12):
     """A random kinematic tree as ModelTables: depth-first body order, 0-3 joints per body (mostly hinges, some with
-    jnt_pos == 0, some slides / balls), random body orientations (some identity), sites on random bodies."""
+    jnt_pos == 0, some slides / balls), random body orientations (some identity), sites on random bodies.
+    lean: what the lean kernels' split kinematics take -- no oriented body, only hinges below the (free) root; some bodies
+    with body_pos == 0."""
     from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE, JNT_HINGE, JNT_SLIDE, ModelTables
 
     parent = [0] * nbody
@@ -674,8 +676,10 @@ def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_
     body_pos = rng.normal(0, 0.05, (nbody, 3))
     body_quat = np.tile([1.0, 0, 0, 0], (nbody, 1))
     for b in range(1, nbody):
-        if rng.random() < 0.4:
+        if not lean and rng.random() < 0.4:
             body_quat[b] = unit(rng.normal(0, 1, 4))
+        if lean and rng.random() < 0.15:
+            body_pos[b] = 0.0
     jt, jadr_q, jbody, jpos, jaxis, jrange, qpos0 = [], [], [], [], [], [], []
     body_jntadr, body_jntnum = [-1] * nbody, [0] * nbody
     nq = 0
@@ -707,7 +711,7 @@ def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_
                 qpos0.append(float(rng.normal(0, 0.05)) if rng.random() < 0.3 else 0.0)
                 jrange.append([-1.0, 1.2] if ty == JNT_HINGE else [-0.05, 0.05])
                 nq += 1
-    K = int(rng.integers(3, 12))
+    K = int(rng.integers(3, k_max))
     site_body = np.sort(rng.integers(1, nbody, K)).astype(np.int32)
     return ModelTables(
         nbody=nbody, njnt=len(jt), nq=nq, nsite=K, body_parentid=np.array(parent, np.int32),
@@ -772,6 +776,64 @@ def test_random_models_bit_exact(seed):
             np.testing.assert_array_equal(_np(fk["site_xpos"][i]), o["site_xpos"])
         res = eng.q_phase(kp, part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=do_root)
         _compare_phase(res, ref)
+
+
+def _random_lean_case(seed, chains=6, frames=2, maxiter=10):
+    """One random model of the kind the lean kernels take (free root, hinges, no oriented body: split kinematics with
+    host-scheduled passes -- restarts, bodies / joints without offset, pruned root programs) through every lean launch site,
+    each launched twice, against the oracle at tolerance 0.  Returns how many of the launches ran a lean kernel."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+    from stac_mjx_amd.mjcf import JNT_FREE
+
+    rng = np.random.default_rng(90000 + seed)
+    nbody = int(rng.integers(3, (25, 45, 70)[seed % 3]))
+    t = _random_tables(rng, nbody, True, p_slide=0.0, p_ball=0.0, max_children_bias=float(rng.choice([0.3, 0.6, 0.9, 0.97])), lean=True,
+                       k_max=int(rng.choice([6, 12, 30])))
+    if t.nq > 80:  # (the lean instantiations hold 80 coordinates at 16 lanes, 96 at 32)
+        pytest.skip("more coordinates than the lean kernels hold")
+    nq, K = t.nq, t.nsite
+    lb, ub = np.full(nq, -np.inf, np.float32), np.full(nq, np.inf, np.float32)
+    for j in range(t.njnt):
+        a, ty = int(t.jnt_qposadr[j]), int(t.jnt_type[j])
+        if ty == JNT_FREE:
+            lb[a + 3:a + 7], ub[a + 3:a + 7] = -1, 1
+        else:
+            lb[a], ub[a] = min(t.jnt_range[j, 0], 0.0), t.jnt_range[j, 1]
+    tol = float(rng.choice([1e-5, 1e-3]))
+    orc = Oracle(t, tol=tol, maxiter=maxiter)
+    n = chains * frames
+    q = np.tile(t.qpos0, (n, 1)) + rng.normal(0, 0.15, (n, nq)).astype(np.float32)
+    q = np.clip(q, np.where(np.isfinite(lb), lb, -3), np.where(np.isfinite(ub), ub, 3)).astype(np.float32)
+    kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32)
+    kp = (kp + rng.normal(0, 2e-3, kp.shape)).astype(np.float32).reshape(chains, frames, 3 * K)
+    P = int(rng.integers(0, 4))
+    part = np.zeros((P, nq), np.uint8)
+    for i in range(P):
+        part[i] = rng.random(nq) < rng.choice([0.15, 0.5])
+    trunk = (rng.random(K) < 0.6).astype(np.uint8)
+    trunk[0] = 1
+    kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=True)
+    ref = orc.ik_clips(kp, lb, ub, part, trunk, 0, 7, do_root_opt=True)
+    lean_runs = 0
+    for lanes in (16, 32, 0):
+        eng = Engine(t, lb, ub, tol=tol, maxiter=maxiter, lanes_per_chain=lanes)
+        res = _q_phase_twice(eng, kp, **kw)
+        lean_runs += _last_q_kernel(eng)[3] & 1
+        np.testing.assert_array_equal(res["qpos"].cpu().numpy().view(np.uint32), ref["qpos"].view(np.uint32), err_msg=f"seed {seed} lanes {lanes}")
+        np.testing.assert_array_equal(res["counters"].cpu().numpy(), ref["counters"])
+    return lean_runs
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_lean_models_bit_exact(seed):
+    """Round 5: random trees of the lean kind (no generator of the other fuzz tests ever draws one: 40 % oriented bodies) -- the
+    host's list scheduler of the split kinematics meets chains, bushes, zero offsets and root programs of every shape."""
+    _random_lean_case(seed)
+
+
+def test_random_lean_models_do_take_the_lean_kernels():
+    assert sum(_random_lean_case(s) for s in (100, 101, 102)) >= 6  # (three launches per model)
 
 
 def _random_model_case(seed, nbody_lo, nbody_hi, chains, frames, lanes_list, maxiter=10, q_init=False):

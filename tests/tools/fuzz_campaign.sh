@@ -18,6 +18,11 @@ for sw in STAC_HIP_SPEC=0 "STAC_HIP_SPEC=1 STAC_HIP_SPECG=32" "STAC_HIP_SPEC=1 S
           "STAC_HIP_HANDOFF=8 STAC_HIP_SPEC=0" STAC_HIP_FLAGS=2 STAC_HIP_NOFAST=1; do
   run $NB big $sw
 done
+run $((2*NS)) lean X=1
+for sw in STAC_HIP_SPEC=0 STAC_HIP_NOFAST=1 STAC_HIP_NOPRUNE=1 "STAC_HIP_QUEUE=8 STAC_HIP_SPEC=0" "STAC_HIP_HANDOFF=8 STAC_HIP_SPEC=0" \
+          "STAC_HIP_SPEC=1 STAC_HIP_SPECG=16" "STAC_HIP_SPEC=1 STAC_HIP_SPECG=16 STAC_HIP_SPECR=8" "STAC_HIP_SPEC=1 STAC_HIP_SPECG=32"; do
+  run $NS lean $sw
+done
 echo "== LM" >> $out
 timeout 900 python tests/fuzz_lm_random_models.py $NB 2>&1 | grep -v amdgpu.ids | tail -2 >> $out
 cat $out
