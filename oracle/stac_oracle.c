@@ -548,26 +548,33 @@ void orc_m_opt(const orc_model *m, const float *keypoints, const float *q, int32
  * Optional fast solver: projected Levenberg-Marquardt (see stac_oracle.h).  NOT the reference's algorithm.
  * ============================================================================================================ */
 typedef struct {
-    int nd;          /* optimised coordinates with structural support (ancestor of a fit site) */
+    int nd;          /* optimised coordinates with structural support (ancestor of a fit site), in qpos order */
+    int maxpd;       /* longest root path, counted in such coordinates */
     int *dof;        /* [nd] qpos indices, increasing */
     int *dof_jnt;    /* [nd] joint of each coordinate */
-    real *J;         /* [3K, nd] dx/dq */
-    real *A, *H;     /* [nd, nd] */
-    real *b, *d, *bb;/* [nd] */
+    int *pd;         /* [nd] position of the coordinate on its own root path = number of earlier coordinates on it */
+    int *path;       /* [nd, nq] the coordinates of its root path, itself last (path[a][pd[a]] == a) */
+    real *J;         /* [K sorted positions, nd, 3] weighted Jacobian blocks d(site)/d(coordinate) */
+    real *A, *H;     /* [nd, nd]; only entries (row, column on the row's root path) are used */
+    real *b, *d, *l; /* [nd] right-hand side, step, the pivot's multipliers */
+    real *term;      /* [K + 4] per-site loss terms */
     unsigned char *frozen;
 } lm_ws_t;
 
 static lm_ws_t *lm_new(const orc_model *m) {
     lm_ws_t *l = (lm_ws_t *)calloc(1, sizeof(lm_ws_t));
     const int nq = m->nq, K = m->nsite;
-    l->dof = (int *)calloc(2 * (size_t)nq, sizeof(int));
+    l->dof = (int *)calloc(3 * (size_t)nq + (size_t)nq * nq, sizeof(int));
     l->dof_jnt = l->dof + nq;
-    l->J = (real *)calloc((size_t)3 * K * nq + 2 * (size_t)nq * nq + 3 * (size_t)nq, sizeof(real));
+    l->pd = l->dof_jnt + nq;
+    l->path = l->pd + nq;
+    l->J = (real *)calloc((size_t)3 * K * nq + 2 * (size_t)nq * nq + 3 * (size_t)nq + K + 4, sizeof(real));
     l->A = l->J + (size_t)3 * K * nq;
     l->H = l->A + (size_t)nq * nq;
     l->b = l->H + (size_t)nq * nq;
     l->d = l->b + nq;
-    l->bb = l->d + nq;
+    l->l = l->d + nq;
+    l->term = l->l + nq;
     l->frozen = (unsigned char *)calloc(nq, 1);
     return l;
 }
@@ -575,80 +582,63 @@ static void lm_free(lm_ws_t *l) {
     if (l) { free(l->dof); free(l->J); free(l->frozen); free(l); }
 }
 
-/* Site Jacobian columns at the pose of the last fk_ws (w->qf normalised, anchors, axes, jnorm filled). */
-static void lm_jacobian(const orc_model *m, ws_t *w, lm_ws_t *l) {
-    const int K = m->nsite, nd = l->nd;
-    for (size_t i = 0; i < (size_t)3 * K * nd; ++i) l->J[i] = R(0);
-    for (int c = 0; c < nd; ++c) {
-        const int j = l->dof_jnt[c], b = m->jnt_bodyid[j], a = m->jnt_qposadr[j], comp = l->dof[c] - a;
-        const real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
-        for (int i = w->blo[b]; i < w->bhi[b]; ++i) { /* sites of the joint's body subtree */
-            const int k = w->sord[i];
-            real dvec[3], col[3];
-            for (int t = 0; t < 3; ++t) dvec[t] = w->sx[3 * k + t] - anchor[t];
-            switch (m->jnt_type[j]) {
-            case ORC_JNT_HINGE: cross3(axis, dvec, col); break;
-            case ORC_JNT_SLIDE: col[0] = axis[0]; col[1] = axis[1]; col[2] = axis[2]; break;
-            case ORC_JNT_FREE:
-                if (comp < 3) { col[0] = comp == 0; col[1] = comp == 1; col[2] = comp == 2; }
-                else {
-                    /* raw quaternion (s,u), q^ = q/|q|: dx/ds = -2 (u^ x d)/|q|, dx/du_j = 2 (s^ (e_j x d) - (e_j x u^) x d)/|q| */
-                    const real *qh = w->qf + a + 3;
-                    const real n = w->jnorm[j], dn = n + (n == R(0) ? R(1e-6) : R(0));
-                    if (comp == 3) {
-                        cross3(qh + 1, dvec, col);
-                        for (int t = 0; t < 3; ++t) col[t] = (R(-2) * col[t]) / dn;
-                    } else {
-                        real e[3] = {R(0), R(0), R(0)}, exd[3], exu[3], t2[3];
-                        e[comp - 4] = R(1);
-                        cross3(e, dvec, exd);
-                        cross3(e, qh + 1, exu);
-                        cross3(exu, dvec, t2);
-                        for (int t = 0; t < 3; ++t) col[t] = (R(2) * (qh[0] * exd[t] - t2[t])) / dn;
-                    }
-                }
-                break;
-            default: col[0] = col[1] = col[2] = R(0); break; /* ball: unsupported */
+/* One column of the 3 x nd site Jacobian at the pose of the last fk_ws (w->qf normalised, anchors, axes, jnorm filled):
+ * stac_lm.hip, jac_col, operation for operation. */
+static void lm_jac_col(const orc_model *m, const ws_t *w, int j, int comp, const real *sx, real *col) {
+    const real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
+    real dvec[3];
+    for (int t = 0; t < 3; ++t) dvec[t] = sx[t] - anchor[t];
+    switch (m->jnt_type[j]) {
+    case ORC_JNT_HINGE: cross3(axis, dvec, col); break;
+    case ORC_JNT_SLIDE: col[0] = axis[0]; col[1] = axis[1]; col[2] = axis[2]; break;
+    case ORC_JNT_FREE:
+        if (comp < 3) { col[0] = comp == 0; col[1] = comp == 1; col[2] = comp == 2; }
+        else {
+            /* raw quaternion (s,u), q^ = q/|q|: dx/ds = -2 (u^ x d)/|q|, dx/du_j = 2 (s^ (e_j x d) - (e_j x u^) x d)/|q| */
+            const real *qh = w->qf + m->jnt_qposadr[j] + 3;
+            const real n = w->jnorm[j], dn = n + (n == R(0) ? R(1e-6) : R(0));
+            if (comp == 3) {
+                cross3(qh + 1, dvec, col);
+                for (int t = 0; t < 3; ++t) col[t] = (R(-2) * col[t]) / dn;
+            } else {
+                real e[3] = {R(0), R(0), R(0)}, exd[3], exu[3], t2[3];
+                e[comp - 4] = R(1);
+                cross3(e, dvec, exd);
+                cross3(e, qh + 1, exu);
+                cross3(exu, dvec, t2);
+                for (int t = 0; t < 3; ++t) col[t] = (R(2) * (qh[0] * exd[t] - t2[t])) / dn;
             }
-            for (int t = 0; t < 3; ++t) l->J[(size_t)(3 * k + t) * nd + c] = col[t];
         }
+        break;
+    default: col[0] = col[1] = col[2] = R(0); break; /* ball: unsupported */
     }
 }
 
-/* In-place dense Cholesky solve of the SPD system H d = bb (nd x nd, row-major, lower triangle used). */
-static int lm_chol_solve(int n, real *H, const real *bb, real *d) {
-    for (int j = 0; j < n; ++j) {
-        real s = H[(size_t)j * n + j];
-        for (int k = 0; k < j; ++k) s -= H[(size_t)j * n + k] * H[(size_t)j * n + k];
-        if (!(s > R(0))) return -1;
-        const real ljj = rsqrt_(s);
-        H[(size_t)j * n + j] = ljj;
-        for (int i = j + 1; i < n; ++i) {
-            real t = H[(size_t)i * n + j];
-            for (int k = 0; k < j; ++k) t -= H[(size_t)i * n + k] * H[(size_t)j * n + k];
-            H[(size_t)i * n + j] = t / ljj;
-        }
+/* The LM kernel's loss of the pose of the last fk_ws: the per-site terms in site order, summed four at a time (zeros behind the last). */
+static real lm_loss(const orc_model *m, const ws_t *w, lm_ws_t *l, const uint8_t *kps_to_opt) {
+    const int K = m->nsite, Kpad = (K + 3) & ~3;
+    for (int k = 0; k < K; ++k) {
+        real r[3];
+        for (int i = 0; i < 3; ++i) r[i] = (w->kp[3 * k + i] - w->sx[3 * k + i]) * (kps_to_opt[3 * k + i] ? R(1) : R(0));
+        l->term[k] = FMA(r[2], r[2], FMA(r[1], r[1], r[0] * r[0]));
     }
-    for (int i = 0; i < n; ++i) {
-        real t = bb[i];
-        for (int k = 0; k < i; ++k) t -= H[(size_t)i * n + k] * d[k];
-        d[i] = t / H[(size_t)i * n + i];
-    }
-    for (int i = n - 1; i >= 0; --i) {
-        real t = d[i];
-        for (int k = i + 1; k < n; ++k) t -= H[(size_t)k * n + i] * d[k];
-        d[i] = t / H[(size_t)i * n + i];
-    }
-    return 0;
+    for (int k = K; k < Kpad; ++k) l->term[k] = R(0);
+    real loss = R(0);
+    for (int i = 0; i < Kpad; i += 4) loss += (l->term[i] + l->term[i + 1]) + (l->term[i + 2] + l->term[i + 3]);
+    return loss;
 }
 
+/* stac_lm.hip::q_phase_lm_kernel, one solve, operation for operation: the same evaluation (FK, gradient), the kernel's loss sum, the
+ * Gauss-Newton entries over DFS-ordered site ranges, the damping, the L^T D L factorisation on root paths (leaves first, no fill-in), the
+ * substitutions, the clipped step and the accept / reject turns -- including what the kernel does when the damped matrix is not
+ * positive definite (the step is the point itself: one more evaluation, one more rejection). */
 static void q_opt_lm_ws(const orc_model *m, ws_t *w, lm_ws_t *l, const orc_lm_params *p, const uint8_t *qs_to_opt,
                         const uint8_t *kps_to_opt, orc_pg_state *st) {
     /* inputs in w->q0 (start AND initial_q), w->kp, w->lb, w->ub; result in w->x */
     const int nq = m->nq, K = m->nsite;
     real *x = w->x, *xt = w->cand, *g = w->g;
     for (int i = 0; i < nq; ++i) x[i] = w->q0[i];
-    /* coordinates: optimised AND on the root path of some fit site */
+    /* coordinates: optimised AND on the root path of some fit site, in qpos order; their root paths */
     l->nd = 0;
     for (int j = 0; j < m->njnt; ++j) {
         const int b = m->jnt_bodyid[j], a = m->jnt_qposadr[j];
@@ -658,74 +648,133 @@ static void q_opt_lm_ws(const orc_model *m, ws_t *w, lm_ws_t *l, const orc_lm_pa
             if (qs_to_opt[a + c]) { l->dof[l->nd] = a + c; l->dof_jnt[l->nd] = j; l->nd++; }
     }
     const int nd = l->nd;
+    l->maxpd = 1;
+    for (int b2 = 0; b2 < nd; ++b2) {
+        const int bb = m->jnt_bodyid[l->dof_jnt[b2]];
+        int np = 0;
+        for (int a2 = 0; a2 <= b2; ++a2) {
+            int on_path = a2 == b2;
+            for (int s2 = bb; s2 > 0 && !on_path; s2 = m->body_parentid[s2]) on_path = s2 == m->jnt_bodyid[l->dof_jnt[a2]];
+            if (on_path) l->path[(size_t)b2 * nq + np++] = a2;
+        }
+        l->pd[b2] = np - 1;
+        if (np > l->maxpd) l->maxpd = np;
+    }
     real lam = R(p->lambda0);
-    int iter = 0, evals = 0, gevals = 0;
-    real f = q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, g);
+    int iter = 0, evals = 0, gevals = 0, tries = 0;
+    (void)q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, g);
+    real f = lm_loss(m, w, l, kps_to_opt);
     ++gevals;
     real error = (real)INFINITY;
     for (;;) {
-        /* stopping residual, same definition as the PG solver */
+        /* stopping residual of the accepted point, same definition as the PG solver */
         for (int i = 0; i < nq; ++i) { const real dd = clipr(x[i] - g[i], w->lb[i], w->ub[i]) - x[i]; w->tb0[i] = dd * dd; }
         error = rsqrt_(tree_sum(w->tb0, nq));
         if (!(error > R(p->tol)) || iter >= p->maxiter || nd == 0) break;
-        /* Gauss-Newton system at x (fk_ws state is that of x: the last q_loss_ws call evaluated x) */
-        lm_jacobian(m, w, l);
-        for (int a = 0; a < nd; ++a) {
-            for (int b2 = 0; b2 <= a; ++b2) {
-                real s = R(0);
-                for (int r = 0; r < 3 * K; ++r)
-                    if (kps_to_opt[r]) s += l->J[(size_t)r * nd + a] * l->J[(size_t)r * nd + b2];
-                l->A[(size_t)a * nd + b2] = s;
-                l->A[(size_t)b2 * nd + a] = s;
+        /* Gauss-Newton system at x (fk_ws state is that of x: the last evaluation was the accepted point) */
+        for (int b2 = 0; b2 < nd; ++b2) {
+            const int j = l->dof_jnt[b2], bb = m->jnt_bodyid[j];
+            for (int i = w->blo[bb]; i < w->bhi[bb]; ++i) { /* sites of the joint's body subtree, by sorted position */
+                const int k = w->sord[i];
+                real col[3];
+                lm_jac_col(m, w, j, l->dof[b2] - m->jnt_qposadr[j], w->sx + 3 * k, col);
+                const real wk = kps_to_opt[3 * k] ? R(1) : R(0); /* site weight (0 / 1): the trunk mask in the root passes */
+                for (int t = 0; t < 3; ++t) l->J[((size_t)i * nd + b2) * 3 + t] = col[t] * wk;
             }
-            l->b[a] = R(-0.5) * g[l->dof[a]];
+        }
+        for (int b2 = 0; b2 < nd; ++b2) {
+            const int bb = m->jnt_bodyid[l->dof_jnt[b2]];
+            for (int pi = 0; pi <= l->pd[b2]; ++pi) {
+                const int a2 = l->path[(size_t)b2 * nq + pi];
+                real s = R(0);
+                for (int i = w->blo[bb]; i < w->bhi[bb]; ++i)
+                    s += dot3(l->J + ((size_t)i * nd + b2) * 3, l->J + ((size_t)i * nd + a2) * 3);
+                l->A[(size_t)b2 * nd + a2] = s;
+            }
+            l->b[b2] = R(-0.5) * g[l->dof[b2]];
+            const int e = l->dof[b2];
+            const real xe = w->qf[e]; /* the accepted point as staged (root quaternion normalised) */
+            l->frozen[b2] = (xe <= w->lb[e] && l->b[b2] < R(0)) || (xe >= w->ub[e] && l->b[b2] > R(0));
         }
         /* gauge of the raw root quaternion: its length does not change the pose; make that direction stiff */
-        for (int j = 0; j < m->njnt; ++j) {
-            if (m->jnt_type[j] != ORC_JNT_FREE) continue;
-            int idx[4], have = 1;
-            for (int c = 0; c < 4; ++c) {
-                idx[c] = -1;
-                for (int a = 0; a < nd; ++a) if (l->dof[a] == m->jnt_qposadr[j] + 3 + c) idx[c] = a;
-                if (idx[c] < 0) have = 0;
-            }
-            if (!have) continue;
+        for (int b2 = 0; b2 + 3 < nd; ++b2) {
+            const int j = l->dof_jnt[b2];
+            if (m->jnt_type[j] != ORC_JNT_FREE || l->dof[b2] != m->jnt_qposadr[j] + 3 || l->dof_jnt[b2 + 3] != j ||
+                l->dof[b2 + 3] != m->jnt_qposadr[j] + 6)
+                continue;
             const real *qh = w->qf + m->jnt_qposadr[j] + 3;
-            for (int c = 0; c < 4; ++c) for (int e = 0; e < 4; ++e) l->A[(size_t)idx[c] * nd + idx[e]] += qh[c] * qh[e];
-        }
-        for (int a = 0; a < nd; ++a) {
-            const int i = l->dof[a];
-            l->frozen[a] = (x[i] <= w->lb[i] && l->b[a] < R(0)) || (x[i] >= w->ub[i] && l->b[a] > R(0));
+            for (int c = 0; c < 4; ++c)
+                for (int e = 0; e <= c; ++e) l->A[(size_t)(b2 + c) * nd + b2 + e] += qh[c] * qh[e];
         }
         int accepted = 0;
-        for (int tries = 0; tries < 8 && !accepted; ++tries) {
-            for (int a = 0; a < nd; ++a) {
-                for (int b2 = 0; b2 < nd; ++b2)
-                    l->H[(size_t)a * nd + b2] = (l->frozen[a] || l->frozen[b2]) ? R(0) : l->A[(size_t)a * nd + b2];
-                l->H[(size_t)a * nd + a] = l->frozen[a] ? R(1) : l->A[(size_t)a * nd + a] * (R(1) + lam) + R(1e-9);
-                l->bb[a] = l->frozen[a] ? R(0) : l->b[a];
+        while (!accepted) {
+            /* damped, bound-aware matrix on the root paths; right-hand side */
+            for (int b2 = 0; b2 < nd; ++b2) {
+                for (int pi = 0; pi <= l->pd[b2]; ++pi) {
+                    const int a2 = l->path[(size_t)b2 * nq + pi];
+                    real v = l->A[(size_t)b2 * nd + a2];
+                    if (a2 == b2) v = l->frozen[b2] ? R(1) : FMA(v, lam, v) + R(1e-9);
+                    else if (l->frozen[b2] || l->frozen[a2]) v = R(0);
+                    l->H[(size_t)b2 * nd + a2] = v;
+                }
+                l->d[b2] = l->frozen[b2] ? R(0) : l->b[b2];
             }
-            if (lm_chol_solve(nd, l->H, l->bb, l->d) != 0) { lam = lam * R(4); continue; }
-            for (int i = 0; i < nq; ++i) xt[i] = x[i];
-            for (int a = 0; a < nd; ++a) { const int i = l->dof[a]; xt[i] = clipr(x[i] + l->d[a], w->lb[i], w->ub[i]); }
-            const real ft = q_loss_ws(m, w, xt, w->kp, qs_to_opt, kps_to_opt, w->q0, w->gn);
+            /* L^T D L, leaves first: pivot k scales its row, y = L^-T b on the fly, and updates the rows of its ancestors */
+            int bad = 0;
+            for (int k = nd - 1; k >= 0; --k) {
+                const int pdk = l->pd[k];
+                const int *pk = l->path + (size_t)k * nq;
+                const real dkk = l->H[(size_t)k * nd + k];
+                if (!(dkk > R(0))) bad = 1;
+                const real bk = l->d[k];
+                for (int pi = 0; pi < pdk; ++pi) {
+                    const real lp = l->H[(size_t)k * nd + pk[pi]] / dkk;
+                    l->l[pi] = lp;
+                    l->d[pk[pi]] = FMA(-lp, bk, l->d[pk[pi]]);
+                }
+                for (int pi = 0; pi < pdk; ++pi)
+                    for (int pj = 0; pj <= pi; ++pj) {
+                        const size_t at = (size_t)pk[pi] * nd + pk[pj];
+                        l->H[at] = FMA(-l->l[pi], l->H[(size_t)k * nd + pk[pj]], l->H[at]);
+                    }
+                for (int pi = 0; pi < pdk; ++pi) l->H[(size_t)k * nd + pk[pi]] = l->l[pi];
+            }
+            /* z = D^-1 y, d = L^-1 z: a coordinate only depends on the ones of its own root path (ancestors first) */
+            for (int i = 0; i < nd; ++i) {
+                const int *pi_ = l->path + (size_t)i * nq;
+                real tv = l->d[i] / l->H[(size_t)i * nd + i];
+                for (int lev = 0; lev < l->pd[i]; ++lev) tv = FMA(-l->H[(size_t)i * nd + pi_[lev]], l->d[pi_[lev]], tv);
+                l->d[i] = tv;
+            }
+            real ft;
+            if (bad) { /* not positive definite at this damping: the kernel evaluates the point itself and rejects it */
+                lam = lam * R(4);
+                ft = f;
+            } else {
+                for (int i = 0; i < nq; ++i) xt[i] = x[i];
+                for (int a2 = 0; a2 < nd; ++a2) { const int i = l->dof[a2]; xt[i] = clipr(x[i] + l->d[a2], w->lb[i], w->ub[i]); }
+                (void)q_loss_ws(m, w, xt, w->kp, qs_to_opt, kps_to_opt, w->q0, w->gn);
+                ft = lm_loss(m, w, l, kps_to_opt);
+            }
             ++evals; ++gevals;
-            if (ft < f) {
+            if (!bad && ft < f) {
                 for (int i = 0; i < nq; ++i) { x[i] = xt[i]; g[i] = w->gn[i]; }
                 f = ft;
+                tries = 0;
                 lam = lam * R(0.5);
                 if (lam < R(1e-9)) lam = R(1e-9);
+                ++iter;
                 accepted = 1;
             } else {
                 lam = lam * R(4);
+                if (++tries >= 8) break; /* no decrease found: keep x */
             }
         }
         if (!accepted) {
-            /* no decrease found: restore the fk_ws state of x for the caller and stop */
+            /* restore the fk_ws state of x for the caller and stop */
             (void)q_loss_ws(m, w, x, w->kp, qs_to_opt, kps_to_opt, w->q0, g);
             break;
         }
-        ++iter;
     }
     if (st) {
         st->iter_num = iter;

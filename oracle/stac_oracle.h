@@ -96,11 +96,16 @@ void orc_q_opt(const orc_model *m, const orc_pg_params *p, const float *kp,
 /* ---- optional fast solver (NOT the reference's algorithm) --------------------------------------------------
  * Projected Levenberg-Marquardt on the same objective, bounds and masks as orc_q_opt (the "LM qpos update" of
  * BASELINE.json's north star).  It does not reproduce the reference's truncated
- * projected-gradient iterates and is judged in marker space.  Per iteration: Gauss-Newton matrix A = J^T W J and
- * b = J^T W (kp - x) from analytic site Jacobians, multiplicative damping A_ii (1 + lambda) + mu, bound-active
- * coordinates frozen, dense Cholesky, step clipped to the box, accepted if the loss decreases (lambda /= 2) else
- * lambda *= 4 (at most 8 times in a row).  Stops on the same residual as the PG solver (||clip(x - grad) - x|| <= tol) or after maxiter
- * accepted steps.  Ball joints are not supported. */
+ * projected-gradient iterates and is judged in marker space against them.  It IS the operation sequence of the HIP kernel
+ * (stac_mjx_amd/csrc/stac_lm.hip), so that the GPU tests compare the two bit for bit.  Per iteration: the loss as the sum
+ * of the per-site terms four at a time in site order; Gauss-Newton entries A[b][a] = sum over the DFS-ordered sites below
+ * coordinate b of dot3(J_b, J_a) for the coordinates a on b's root path (others are structurally zero), b = -g / 2, a gauge
+ * term on the raw root quaternion; multiplicative damping fma(A_ii, lambda, A_ii) + 1e-9, bound-active coordinates frozen;
+ * Featherstone's L^T D L on the root paths (pivots in decreasing qpos order: no fill-in), y = L^-T b on the fly,
+ * z = D^-1 y, d = L^-1 z ancestors first; step clipped to the box, accepted if the loss decreases (lambda /= 2) else
+ * lambda *= 4 (at most 8 times in a row; a matrix that is not positive definite counts as a rejected evaluation of the
+ * point itself).  Stops on the same residual as the PG solver (||clip(x - grad) - x|| <= tol) or after maxiter accepted
+ * steps.  Ball joints are not supported. */
 typedef struct {
     float tol;       /* same stopping residual as the PG solver */
     int32_t maxiter; /* accepted steps, e.g. 40 */

@@ -1405,6 +1405,10 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
             for (int c = 0; c < dims; ++c)
                 if (mask[m->h_aj_qadr[j] + c]) D.push_back({m->h_aj_qadr[j] + c, j, c, 0});
         }
+        // qpos order (= the model's joint order: parents before children), whatever the order of the active joints in the plan:
+        // the L^T D L pivots run through the coordinates backwards, and rounding makes their order part of the result --
+        // oracle/stac_oracle.c::q_opt_lm_ws states the same order
+        std::stable_sort(D.begin(), D.end(), [](const Dof &x, const Dof &y) { return x.qadr < y.qadr; });
         const int nd = (int)D.size();
         std::vector<int32_t> ents, items;
         std::vector<std::vector<int>> paths(nd);

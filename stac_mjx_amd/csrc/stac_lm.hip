@@ -3,8 +3,9 @@
 // NOT the reference's algorithm (the reference runs jaxopt.ProjectedGradient, stac_mjx/stac_core.py:182-191,
 // which stac_kernels.hip reproduces bit for bit).  This is the "LM qpos update" of BASELINE.json's north star
 // (SURVEY.md section 7 step 6): same objective, masks, bounds, stopping residual and phase sequencing
-// (compute_stac.py:17-104,170-278), judged in marker space.  oracle/stac_oracle.c::q_opt_lm_ws is its CPU
-// statement; tests compare the two with tolerances (LM iterates are not reproduced bit for bit).
+// (compute_stac.py:17-104,170-278), judged in marker space against the reference's algorithm.  oracle/stac_oracle.c::q_opt_lm_ws
+// is its CPU statement, operation for operation (loss sum, Gauss-Newton entries, pivots, substitutions, accept / reject turns):
+// the GPU tests compare the two bit for bit.
 //
 // Mapping: like the PG kernel a wavefront is split into groups of G lanes, one chain per group, every trip
 // round the main loop evaluates one point per group (FK over the marker-ancestor subtree, site residuals,
