@@ -346,12 +346,14 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
 // operation where there is one -- the running value stays in its registers --, any other operation "restarts" from the LDS
 // entry of its predecessor.  Returns false if the program does not fit (more than 32 steps, offsets beyond 16 bits).
 struct Fk3Program {
-    std::vector<int32_t> words;   // T1 [(cap1 + 2) * 4][4], T2 [cap2][4], T3 [cap3 * 4], site words [K], joint words [naj]
+    std::vector<int32_t> words;   // T1 [(cap1 + 2) * 4][4], T2 [cap2][4], T3 [cap3 * 4] (cap3 + 12 used), site words [K], joint words [naj]
     int n1 = 0, n2 = 0, n3 = 0;
     uint32_t m1 = 0, m3 = 0;
 };
 struct Fk3Op { int prev; int height; int t = -1, pp = -1; bool restart = false; };
-static int fk3_schedule(std::vector<Fk3Op> &ops) {  // returns the number of steps
+// B, D: an operation may restart only in a step t with t % B == 0, and only from a predecessor finished in a step <= t - D (the
+// kernel requests the restart value that far ahead: fk3_p3); a restart from the root position (prev < 0) is always possible.
+static int fk3_schedule(std::vector<Fk3Op> &ops, const int B, const int D) {  // returns the number of steps
     const int n = (int)ops.size(), W = 4;
     for (int i = n - 1; i >= 0; --i) {
         ops[i].height = std::max(ops[i].height, 1);
@@ -368,11 +370,11 @@ static int fk3_schedule(std::vector<Fk3Op> &ops) {  // returns the number of ste
                 if (ops[i].t < 0 && ops[i].prev == last[pp] && (best < 0 || ops[i].height > ops[best].height)) best = i;
             if (best >= 0) { ops[best].t = t; ops[best].pp = pp; taken[pp] = 1; last[pp] = best; ++done; }
         }
-        for (int pp = 0; pp < W; ++pp) {  // free positions take the most urgent operation whose predecessor is finished
+        for (int pp = 0; pp < W && t % B == 0; ++pp) {  // free positions take the most urgent operation whose predecessor is finished
             if (taken[pp]) continue;
             int best = -1;
             for (int i = 0; i < n; ++i)
-                if (ops[i].t < 0 && (ops[i].prev < 0 || (ops[ops[i].prev].t >= 0 && ops[ops[i].prev].t < t)) &&
+                if (ops[i].t < 0 && (ops[i].prev < 0 || (ops[ops[i].prev].t >= 0 && ops[ops[i].prev].t <= t - D)) &&
                     (best < 0 || ops[i].height > ops[best].height))
                     best = i;
             if (best >= 0) { ops[best].t = t; ops[best].pp = pp; ops[best].restart = true; taken[pp] = 1; last[pp] = best; ++done; }
@@ -439,9 +441,11 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
         }
         body_op[s] = cur;
     }
-    const int n1 = fk3_schedule(o1), n3 = fk3_schedule(o3);
+    const int n1 = fk3_schedule(o1, 1, 1);
+    int n3 = fk3_schedule(o3, 4, 5);
+    if (n3 > 0) n3 = (n3 + 3) & ~3;  // P3 runs whole blocks of four steps
     const int n2 = ((int)o3.size() + 31) & ~31;
-    if (n1 < 0 || n3 < 0 || n1 > 32 || n3 > 32 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;
+    if (n1 < 0 || n3 < 0 || n1 > 32 || n3 > 64 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;
     const int root_slot = cap3 * 4, sink_slot = cap3 * 4 + 1;
     auto pbw = [&](int op) { return h3.c3_pb + 3 * (op < 0 ? root_slot : o3[op].t * 4 + o3[op].pp); };
     auto qbw = [&](int node) { return h3.c3_qb + 4 * node; };
@@ -465,9 +469,11 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
         for (int c = 0; c < 3; ++c) r[c] = f2i(rot[i].v[c]);
         r[3] = qbw(rot[i].qnode) | pbw((int)i) << 16;
     }
-    for (int i = 0; i < 4 * cap3; ++i) T3[i] = -1;
+    // T3[4 b + pp]: what position pp starts block b (steps 4 b .. 4 b + 3) from -- the word of a restart value, or bit 31 | any valid
+    // word if it keeps its running value; cap3 / 4 + 3 blocks (P3 requests three blocks ahead) in the table's 4 cap3 words
+    for (int i = 0; i < 4 * cap3; ++i) T3[i] = (int32_t)(0x80000000u | (uint32_t)pbw(-1));
     for (size_t i = 0; i < o3.size(); ++i)
-        if (o3[i].restart) { T3[o3[i].t * 4 + o3[i].pp] = pbw(o3[i].prev); out.m3 |= 1u << o3[i].t; }
+        if (o3[i].restart) T3[o3[i].t + o3[i].pp] = pbw(o3[i].prev);  // (t % 4 == 0: entry 4 (t / 4) + pp)
     for (int k = 0; k < K; ++k) {
         const int sl = m->h_site_slot[k];
         if (need && !need[sl]) { SW[k] = pbw(-1) | qbw(0) << 16; continue; }  // (a site the root passes do not weigh: any valid entry)
@@ -757,9 +763,9 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
             // capacities of a program area: the full program's own sizes (a pruned program is a sub-DAG: it is checked against them)
             Fk3Program probe;
             g.c3_qb = 0; g.c3_pb = 0; g.c3_ql = 0; g.stride3 = 1;
-            ok = build_fk3_program(m, g, nullptr, 32, 4096, 32, probe);
+            ok = build_fk3_program(m, g, nullptr, 32, 4096, 64, probe);
             if (ok) {
-                g.fk3_cap1 = std::max(probe.n1, 1); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 1);
+                g.fk3_cap1 = std::max(probe.n1, 1); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 4);  // (whole blocks of four steps)
                 int o3 = 0;
                 g.c3_qb = o3; o3 += (naj + 1) * 4;                       // (+ 1: the sink of idle P1 positions)
                 g.c3_pb = o3; o3 += ((g.fk3_cap3 * 4 + 4) * 3 + 3) & ~3;  // (step, position) slots, root position, sink, slack of the prefetch

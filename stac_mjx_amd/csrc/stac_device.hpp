@@ -1048,28 +1048,39 @@ __device__ __forceinline__ void fk3_p2(const float *T2, const int n2, float *CBc
         }
     }
 }
-// P3.  The slot of (step t, position pp) is pb + 3 * (4 t + pp); T3[4 t + pp] = restart word | -1.
-__device__ __forceinline__ void fk3_p3(const int *T3, const int n3, const uint32_t mask, float *CBc, const int pb, const Fk3Lane &L) {
+// P3.  The slot of (step t, position pp) is pb + 3 * (4 t + pp).  Blocks of four steps, every block the same instructions: a position
+// either keeps its running value or starts the block from a restart value, T3[4 b + pp] = word of that value, or bit 31 | a valid word.
+// Everything a block reads is requested while the block before it runs -- its four operands, its restart value (the host schedules a
+// restart at least five steps behind the step that wrote the value: fk3_schedule); the restart words come three blocks ahead -- so a
+// lone wavefront pays the LDS round trip once per pass, not once per step.
+__device__ __forceinline__ float fk3_restart_value(const float *base, const int e) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + ((unsigned)e << 2));  // (bits 30, 31 leave: one v_lshl_add)
+}
+__device__ __forceinline__ void fk3_p3(const int *T3, const int nb, float *CBc, const int pb, const Fk3Lane &L) {
     const int cc = L.c ? L.c - 1 : 0;  // (lane 0 of a quad doubles lane 1: the same loads, the same values stored to the same words)
+    const float *base = CBc + cc;
     float *slot = CBc + pb + 3 * L.pp + cc;
     const int *rp = T3 + L.pp;
-    float v = slot[0];
+    int e0 = rp[0], e1 = rp[4], e2 = rp[8];  // (the words two blocks ahead of their use: no block waits for the one it requested last)
+    float v0 = slot[0], v1 = slot[12], v2 = slot[24], v3 = slot[36];
+    float rl = fk3_restart_value(base, e0);
     float p = 0.0f;
-    for (int t = 0; t < n3;) {
-        if ((mask >> t) & 1u) {
-            const int rs = rp[4 * t];
-            const float rl = CBc[(rs >= 0 ? rs : pb) + cc];
-            p = rs >= 0 ? rl : p;
-        }
-        const int te = fk3_seg_end(mask, t + 1, n3);
-#pragma unroll 4
-        for (; t < te; ++t) {
-            const float nv = slot[12];  // (slack behind the last step's slots: the root position, the sink, one more)
-            p = p + v;
-            slot[0] = p;
-            slot += 12;
-            v = nv;
-        }
+#pragma unroll 2
+    for (int b = 0; b < nb; ++b) {
+        const int e3 = rp[4 * b + 12];
+        const float rn = fk3_restart_value(base, e1);  // (before this block's stores: it sees the blocks before this one)
+        const float *ns = slot + (b + 1 < nb ? 48 : 0);
+        const float n0 = ns[0], n1 = ns[12], n2 = ns[24], n3 = ns[36];
+        p = e0 >= 0 ? rl : p;
+        const float s0 = p + v0;
+        const float s1 = s0 + v1;
+        const float s2 = s1 + v2;
+        const float s3 = s2 + v3;
+        slot[0] = s0; slot[12] = s1; slot[24] = s2; slot[36] = s3;
+        p = s3;
+        slot += 48;
+        e0 = e1; e1 = e2; e2 = e3; rl = rn;
+        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
     }
 }
 struct Fk3Prog { const float *T1, *T2; const int *T3, *site; int n1, n2, n3; uint32_t m1, m3; };
@@ -1081,7 +1092,7 @@ __device__ __forceinline__ void fk3_run(const Fk3Prog &G3, float *CBc, const int
     wave_sync();
     fk3_p2<THROUGHPUT>(G3.T2, G3.n2, CBc, lf, gf);
     wave_sync();
-    if (gf == 16 || lf < 16) fk3_p3(G3.T3, G3.n3, G3.m3, CBc, pb, L);
+    if (gf == 16 || lf < 16) fk3_p3(G3.T3, G3.n3 >> 2, CBc, pb, L);
     wave_sync();
 }
 
