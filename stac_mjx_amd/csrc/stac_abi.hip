@@ -346,7 +346,7 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
 // operation where there is one -- the running value stays in its registers --, any other operation "restarts" from the LDS
 // entry of its predecessor.  Returns false if the program does not fit (more than 32 steps, offsets beyond 16 bits).
 struct Fk3Program {
-    std::vector<int32_t> words;   // T1 [(cap1 + 2) * 4][4], T2 [cap2][4], T3 [cap3 * 4] (cap3 + 12 used), site words [K], joint words [naj]
+    std::vector<int32_t> words;   // T1 [16 (cap1 + 2)] (cap1 / 2 + 3 records of 24 words), T2 [cap2][4], T3 [cap3 * 4] (cap3 + 12 used), site words [K], joint words [naj]
     int n1 = 0, n2 = 0, n3 = 0;
     uint32_t m1 = 0, m3 = 0;
 };
@@ -355,9 +355,13 @@ struct Fk3Op { int prev; int height; int t = -1, pp = -1; bool restart = false; 
 // kernel requests the restart value that far ahead: fk3_p3); a restart from the root position (prev < 0) is always possible.
 static int fk3_schedule(std::vector<Fk3Op> &ops, const int B, const int D) {  // returns the number of steps
     const int n = (int)ops.size(), W = 4;
-    for (int i = n - 1; i >= 0; --i) {
-        ops[i].height = std::max(ops[i].height, 1);
-        if (ops[i].prev >= 0) ops[ops[i].prev].height = std::max(ops[ops[i].prev].height, ops[i].height + 1);
+    for (int i = 0; i < n; ++i) ops[i].height = 1;
+    for (bool changed = true; changed;) {  // (copies made by fk3_unshare stand behind their successors: no index order to rely on)
+        changed = false;
+        for (int i = 0; i < n; ++i) {
+            const int p = ops[i].prev;
+            if (p >= 0 && ops[p].height < ops[i].height + 1) { ops[p].height = ops[i].height + 1; changed = true; }
+        }
     }
     std::vector<int> last(W, -2);  // last operation of every position (-2: none yet)
     int done = 0, t = 0;
@@ -382,6 +386,37 @@ static int fk3_schedule(std::vector<Fk3Op> &ops, const int B, const int D) {  //
         if (t > 4 * n + 8) return -1;
     }
     return t;
+}
+// A restart waits for its source (fk3_schedule: D steps, then the next block), so a branch close to the root would hold its whole
+// subtree back.  An operation at depth <= L with several successors therefore gives every successor but the highest its own copy of
+// the chain from the root (same operands, same order: the same bits, computed once more by a position that would idle anyway).
+// copy(i) appends a copy of operation i's payload and is called once per copied operation, in chain order.
+template <class Copy>
+static void fk3_unshare(std::vector<Fk3Op> &ops, const int L, Copy &&copy) {
+    const int n = (int)ops.size();
+    std::vector<int> depth(n, 0), height(n, 1);
+    for (int i = 0; i < n; ++i) depth[i] = (ops[i].prev >= 0 ? depth[ops[i].prev] : 0) + 1;  // (prev < i here)
+    for (int i = n - 1; i >= 0; --i)
+        if (ops[i].prev >= 0) height[ops[i].prev] = std::max(height[ops[i].prev], height[i] + 1);
+    for (int i = 0; i < n; ++i) {
+        if (depth[i] > L) continue;
+        std::vector<int> kids;
+        for (int k = i + 1; k < n; ++k)
+            if (ops[k].prev == i) kids.push_back(k);
+        if (kids.size() < 2) continue;
+        std::stable_sort(kids.begin(), kids.end(), [&](int x, int y) { return height[x] > height[y]; });
+        std::vector<int> chain;
+        for (int j = i; j >= 0; j = ops[j].prev) chain.push_back(j);
+        for (size_t c = 1; c < kids.size(); ++c) {
+            int last = -1;
+            for (int q = (int)chain.size() - 1; q >= 0; --q) {
+                ops.push_back(Fk3Op{last, 0});
+                copy(chain[q]);
+                last = (int)ops.size() - 1;
+            }
+            ops[kids[c]].prev = last;
+        }
+    }
 }
 static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const char *need, int cap1, int cap2, int cap3, Fk3Program &out) {
     const int nab = h3.nab, naj = h3.naj, K = h3.K;
@@ -441,27 +476,42 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
         }
         body_op[s] = cur;
     }
-    const int n1 = fk3_schedule(o1, 1, 1);
+    fk3_unshare(o1, 2, [&](int i) { j_of1.push_back(j_of1[i]); });
+    fk3_unshare(o3, 4, [&](int i) { rot.push_back(rot[i]); });
+    int n1 = fk3_schedule(o1, 2, 3);
+    if (n1 > 0) n1 = (n1 + 1) & ~1;  // P1 runs whole blocks of two steps
     int n3 = fk3_schedule(o3, 4, 5);
     if (n3 > 0) n3 = (n3 + 3) & ~3;  // P3 runs whole blocks of four steps
     const int n2 = ((int)o3.size() + 31) & ~31;
-    if (n1 < 0 || n3 < 0 || n1 > 32 || n3 > 64 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;
+    if (n1 < 0 || n3 < 0 || n1 > 64 || n3 > 64 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;
     const int root_slot = cap3 * 4, sink_slot = cap3 * 4 + 1;
     auto pbw = [&](int op) { return h3.c3_pb + 3 * (op < 0 ? root_slot : o3[op].t * 4 + o3[op].pp); };
     auto qbw = [&](int node) { return h3.c3_qb + 4 * node; };
     if (h3.stride3 >= 65536) return false;
     out.n1 = std::max(n1, 0); out.n2 = n2; out.n3 = n3; out.m1 = out.m3 = 0;
-    // T1: row 0 is a prologue (only its ql word counts), row t + 1 is step t: {ql word of the position's NEXT step, out word,
-    // restart word | -1, -}; one more row behind the last step (P1 fetches a row ahead)
+    // T1, blocks of two steps, 24 words per record: [24 r + 4 pp] = {ql word of step 2 r, of step 2 r + 1, out word of step 2 r - 2, of
+    // 2 r - 1}, [24 r + 16 + 2 pp] = {restart entry of block r - 1, of block r} -- record r + 1 is what block r works from (its out words,
+    // its restart flag, the next block's ql and restart words), record 0 the prologue.  A restart entry: the word of the quaternion the
+    // position starts the block from, or bit 31 | a valid word if it keeps its running value.  cap1 / 2 + 3 records (P1 fetches one
+    // record ahead and runs pairs of blocks); an idle step multiplies by any quaternion into the sink.
     out.words.assign((size_t)16 * (cap1 + 2) + 4 * (size_t)cap2 + 4 * (size_t)cap3 + K + naj, 0);
     int32_t *T1 = out.words.data(), *T2 = T1 + 16 * (cap1 + 2), *T3 = T2 + 4 * cap2, *SW = T3 + 4 * cap3, *JW = SW + K;
-    for (int i = 0; i < 4 * (cap1 + 2); ++i) { T1[4 * i] = h3.c3_ql; T1[4 * i + 1] = qbw(naj); T1[4 * i + 2] = -1; }  // idle: any ql, sink
+    const int nrec1 = cap1 / 2 + 3;
+    if (24 * nrec1 > 16 * (cap1 + 2)) return false;  // (cap1 >= 10: build_plan)
+    for (int r = 0; r < nrec1; ++r)
+        for (int pp = 0; pp < 4; ++pp) {
+            int32_t *w = T1 + 24 * r + 4 * pp, *e = T1 + 24 * r + 16 + 2 * pp;
+            w[0] = w[1] = h3.c3_ql; w[2] = w[3] = qbw(naj);
+            e[0] = e[1] = (int32_t)(0x80000000u | (uint32_t)qbw(0));
+        }
     for (size_t i = 0; i < o1.size(); ++i) {
-        const int j = j_of1[i];
-        T1[4 * (o1[i].t * 4 + o1[i].pp)] = h3.c3_ql + 4 * j;  // (the row in front of the step's own)
-        int32_t *r = T1 + 4 * ((o1[i].t + 1) * 4 + o1[i].pp);
-        r[1] = qbw(j);
-        if (o1[i].restart) { r[2] = qbw(pre[j]); out.m1 |= 1u << o1[i].t; }
+        const int j = j_of1[i], blk = o1[i].t >> 1, k = o1[i].t & 1, pp = o1[i].pp;
+        T1[24 * blk + 4 * pp + k] = h3.c3_ql + 4 * j;
+        T1[24 * (blk + 1) + 4 * pp + 2 + k] = qbw(j);
+        if (o1[i].restart) {  // (only in the first step of a block: fk3_schedule)
+            T1[24 * blk + 16 + 2 * pp + 1] = qbw(pre[j]);
+            T1[24 * (blk + 1) + 16 + 2 * pp] = qbw(pre[j]);
+        }
     }
     for (int i = 0; i < cap2; ++i) { T2[4 * i + 3] = qbw(0) | (h3.c3_pb + 3 * sink_slot) << 16; }  // no-op: rotate(0, root quaternion) into the sink
     for (size_t i = 0; i < o3.size(); ++i) {
@@ -763,9 +813,10 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
             // capacities of a program area: the full program's own sizes (a pruned program is a sub-DAG: it is checked against them)
             Fk3Program probe;
             g.c3_qb = 0; g.c3_pb = 0; g.c3_ql = 0; g.stride3 = 1;
-            ok = build_fk3_program(m, g, nullptr, 32, 4096, 64, probe);
+            ok = build_fk3_program(m, g, nullptr, 64, 4096, 64, probe);
             if (ok) {
-                g.fk3_cap1 = std::max(probe.n1, 1); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 4);  // (whole blocks of four steps)
+                // (cap1 even, >= 10: the table area 16 (cap1 + 2) holds cap1 / 2 + 3 records of 24 words; cap3: whole blocks)
+                g.fk3_cap1 = std::max(probe.n1, 10); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 4);
                 int o3 = 0;
                 g.c3_qb = o3; o3 += (naj + 1) * 4;                       // (+ 1: the sink of idle P1 positions)
                 g.c3_pb = o3; o3 += ((g.fk3_cap3 * 4 + 4) * 3 + 3) & ~3;  // (step, position) slots, root position, sink, slack of the prefetch

@@ -977,46 +977,50 @@ __device__ __forceinline__ float fk3_qmul(const float qc, const float ql, const 
         : "v"(qc), "v"(ql), "v"(L.m1), "v"(L.m2), "v"(L.m3));
     return r;
 }
-// Steps [t, end) of a pass without a restart: the next flagged step at or behind `from`, or n
-__device__ __forceinline__ int fk3_seg_end(const uint32_t mask, const int from, const int n) {
-    const uint32_t rest = from < 32 ? (mask >> from) << from : 0u;
-    return rest ? min(__builtin_ctz(rest), n) : n;
+// P1.  Blocks of two steps, every block the same instructions (as P3 below): a position keeps its running quaternion or starts the
+// block from a restart value.  T1: records of 24 words (layout: build_fk3_program, stac_abi.hip); block r works from record r + 1 --
+// its out words and restart flag, the ql and restart words of block r + 1 --, so a block's joint-local quaternions and its restart
+// value are requested while the block before it runs (the host schedules a restart at least three steps behind the step that wrote
+// the value) and its record a block before that.  Two blocks per trip, the two sets of registers in turn: nothing is copied.
+__device__ __forceinline__ float fk3_restart_value(const float *base, const int e) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + ((unsigned)e << 2));  // (bits 30, 31 leave: one v_lshl_add)
 }
-// P1.  T1: rows of four records {ql word of the NEXT step, out word, restart word | -1, -}; row 0 is the prologue, row t + 1 step t.
-// mask bit t: some position restarts in step t (then every position runs the select; the others keep their value).
-__device__ __forceinline__ void fk3_p1(const float *T1, const int n1, const uint32_t mask, float *CBc, const Fk3Lane &L) {
-    const float *rp = T1 + 4 * L.pp;
-    float ql = CBc[__builtin_bit_cast(int, rp[0]) + L.c];
-    rp += 16;
-    int4 rec = lds4i(rp);
+__device__ __forceinline__ int2 lds2i(const float *p) { return *reinterpret_cast<const int2 *>(p); }
+__device__ __forceinline__ void fk3_p1(const float *T1, const int nb, float *CBc, const Fk3Lane &L) {
+    float *base = CBc + L.c;
+    const float *rp = T1 + 4 * L.pp, *ep = T1 + 16 + 2 * L.pp;
+    int4 Ra = lds4i(rp);
+    int2 Pa = lds2i(ep);
+    int4 Rb = lds4i(rp + 24);
+    int2 Pb = lds2i(ep + 24);
+    float qa = base[Ra.x], qb = base[Ra.y];
+    float rl = fk3_restart_value(base, Pa.y);
     float qc = 0.0f;
-    for (int t = 0; t < n1;) {
-        if ((mask >> t) & 1u) {
-            const float rl = CBc[(rec.z >= 0 ? rec.z : rec.y) + L.c];
-            qc = rec.z >= 0 ? rl : qc;
+    for (int b = 0; b < nb; b += 2) {  // (an odd count runs one idle block: into the sink)
+        rp += 48; ep += 48;
+        {   // block b: record b + 1 in Rb / Pb, its quaternions in qa, qb, rl
+            Ra = lds4i(rp);
+            Pa = lds2i(ep);
+            const float na = base[Rb.x], nq = base[Rb.y];
+            const float rn = fk3_restart_value(base, Pb.y);  // (before this block's stores: it sees the blocks before this one)
+            qc = Pb.x >= 0 ? rl : qc;
+            const float q1 = fk3_qmul(qc, qa, L);
+            base[Rb.z] = q1;
+            qc = fk3_qmul(q1, qb, L);
+            base[Rb.w] = qc;
+            qa = na; qb = nq; rl = rn;
         }
-        const int te = fk3_seg_end(mask, t + 1, n1);
-        // two steps per trip, the records in turn in `rec` and `rec2`: nothing is copied from one step to the next
-        for (; t + 2 <= te; t += 2) {
-            const int4 rec2 = lds4i(rp + 16);
-            const float ql2 = CBc[rec.x + L.c];
-            const float q1 = fk3_qmul(qc, ql, L);
-            CBc[rec.y + L.c] = q1;
-            rp += 32;
-            rec = lds4i(rp);
-            ql = CBc[rec2.x + L.c];
-            qc = fk3_qmul(q1, ql2, L);
-            CBc[rec2.y + L.c] = qc;
-        }
-        if (t < te) {
-            rp += 16;
-            const int4 nrec = lds4i(rp);
-            const float nql = CBc[rec.x + L.c];
-            qc = fk3_qmul(qc, ql, L);
-            CBc[rec.y + L.c] = qc;
-            rec = nrec;
-            ql = nql;
-            ++t;
+        {   // block b + 1: record b + 2 in Ra / Pa
+            Rb = lds4i(rp + 24);
+            Pb = lds2i(ep + 24);
+            const float na = base[Ra.x], nq = base[Ra.y];
+            const float rn = fk3_restart_value(base, Pa.y);
+            qc = Pa.x >= 0 ? rl : qc;
+            const float q1 = fk3_qmul(qc, qa, L);
+            base[Ra.z] = q1;
+            qc = fk3_qmul(q1, qb, L);
+            base[Ra.w] = qc;
+            qa = na; qb = nq; rl = rn;
         }
     }
 }
@@ -1053,9 +1057,6 @@ __device__ __forceinline__ void fk3_p2(const float *T2, const int n2, float *CBc
 // Everything a block reads is requested while the block before it runs -- its four operands, its restart value (the host schedules a
 // restart at least five steps behind the step that wrote the value: fk3_schedule); the restart words come three blocks ahead -- so a
 // lone wavefront pays the LDS round trip once per pass, not once per step.
-__device__ __forceinline__ float fk3_restart_value(const float *base, const int e) {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + ((unsigned)e << 2));  // (bits 30, 31 leave: one v_lshl_add)
-}
 __device__ __forceinline__ void fk3_p3(const int *T3, const int nb, float *CBc, const int pb, const Fk3Lane &L) {
     const int cc = L.c ? L.c - 1 : 0;  // (lane 0 of a quad doubles lane 1: the same loads, the same values stored to the same words)
     const float *base = CBc + cc;
@@ -1083,12 +1084,12 @@ __device__ __forceinline__ void fk3_p3(const int *T3, const int nb, float *CBc, 
         v0 = n0; v1 = n1; v2 = n2; v3 = n3;
     }
 }
-struct Fk3Prog { const float *T1, *T2; const int *T3, *site; int n1, n2, n3; uint32_t m1, m3; };
+struct Fk3Prog { const float *T1, *T2; const int *T3, *site; int n1, n2, n3; };
 // all three passes; lf = lane in the group of gf lanes (16 or 32; the first 16 run P1 and P3); THROUGHPUT: not a latency kernel
 template <bool THROUGHPUT>
 __device__ __forceinline__ void fk3_run(const Fk3Prog &G3, float *CBc, const int pb, const int lf, const int gf) {
     const Fk3Lane L = fk3_lane(lf & 15);
-    if (gf == 16 || lf < 16) fk3_p1(G3.T1, G3.n1, G3.m1, CBc, L);
+    if (gf == 16 || lf < 16) fk3_p1(G3.T1, G3.n1 >> 1, CBc, L);
     wave_sync();
     fk3_p2<THROUGHPUT>(G3.T2, G3.n2, CBc, lf, gf);
     wave_sync();

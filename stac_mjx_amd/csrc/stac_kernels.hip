@@ -638,10 +638,23 @@ void q_phase_kernel(const QArgs a_in) {
             G3.n1 = rootp ? a.fk3r_n1 : H.fk3_n1;
             G3.n2 = rootp ? a.fk3r_n2 : H.fk3_n2;
             G3.n3 = rootp ? a.fk3r_n3 : H.fk3_n3;
-            G3.m1 = (uint32_t)(rootp ? a.fk3r_m1 : H.fk3_m1);
-            G3.m3 = (uint32_t)(rootp ? a.fk3r_m3 : H.fk3_m3);
             site3 = G3.site;
+#if defined(STAC_PROFILE) && defined(STAC_PROF_FK3)  // (diagnostic: the three passes charged to stamps 2, 4 and 9)
+            {
+                const Fk3Lane L3 = fk3_lane(lg & 15);
+                if (G == 16 || lg < 16) fk3_p1(G3.T1, G3.n1 >> 1, CB, L3);
+                wave_sync();
+                PROF_TICK(2);
+                fk3_p2<(SPEC == 0 && G == 16)>(G3.T2, G3.n2, CB, lg, G);
+                wave_sync();
+                PROF_TICK(4);
+                if (G == 16 || lg < 16) fk3_p3(G3.T3, G3.n3 >> 2, CB, H.c3_pb, L3);
+                wave_sync();
+                PROF_TICK(9);
+            }
+#else
             fk3_run<(SPEC == 0 && G == 16)>(G3, CB, H.c3_pb, lg, G);
+#endif
         } else {
             fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root, a.n_run_root);
         }
