@@ -996,7 +996,7 @@ __device__ __forceinline__ void fk3_p1(const float *T1, const int nb, float *CBc
     float qa = base[Ra.x], qb = base[Ra.y];
     float rl = fk3_restart_value(base, Pa.y);
     float qc = 0.0f;
-    for (int b = 0; b < nb; b += 2) {  // (an odd count runs one idle block: into the sink)
+    for (int b = 0; b + 2 <= nb; b += 2) {
         rp += 48; ep += 48;
         {   // block b: record b + 1 in Rb / Pb, its quaternions in qa, qb, rl
             Ra = lds4i(rp);
@@ -1023,6 +1023,12 @@ __device__ __forceinline__ void fk3_p1(const float *T1, const int nb, float *CBc
             qa = na; qb = nq; rl = rn;
         }
     }
+    if (nb & 1) {  // the last block of an odd count: nothing left to request
+        qc = Pb.x >= 0 ? rl : qc;
+        const float q1 = fk3_qmul(qc, qa, L);
+        base[Rb.z] = q1;
+        base[Rb.w] = fk3_qmul(q1, qb, L);
+    }
 }
 // P2.  T2: tasks {v.x, v.y, v.z, quaternion word | result word << 16}, n2 a multiple of 32 (no-op tasks at the end).  PAIR (throughput
 // kernels at 16 lanes): two rounds of lanes at once -- their loads in flight together, their arithmetic, chains of dependent
@@ -1042,13 +1048,19 @@ __device__ __forceinline__ void fk3_p2(const float *T2, const int n2, float *CBc
             ob[0] = rb.x; ob[1] = rb.y; ob[2] = rb.z;
         }
     } else {
+        // (a lone wavefront waits out every LDS round trip: a round's task comes two rounds ahead, its quaternion one; the rounds
+        //  behind the last one read the last round again)
+        const float *tp = T2 + 4 * lf;
+        const int last = n2 - gf;
+        float4 tk = lds4(tp), tn = lds4(tp + 4 * min(gf, last));
+        float4 q4 = lds4(CBc + (__builtin_bit_cast(int, tk.w) & 0xFFFF));  // (w, x, y, z)
         for (int i0 = 0; i0 < n2; i0 += gf) {
-            const float4 tk = lds4(T2 + 4 * (i0 + lf));
-            const int w = __builtin_bit_cast(int, tk.w);
-            const float4 q4 = lds4(CBc + (w & 0xFFFF));  // (w, x, y, z)
+            const float4 tnn = lds4(tp + 4 * min(i0 + 2 * gf, last));
+            const float4 qn = lds4(CBc + (__builtin_bit_cast(int, tn.w) & 0xFFFF));
             const V3 r = rotate(V3{tk.x, tk.y, tk.z}, Q4{q4.x, q4.y, q4.z, q4.w});
-            float *o = CBc + (int)((unsigned)w >> 16);
+            float *o = CBc + (int)((unsigned)__builtin_bit_cast(int, tk.w) >> 16);
             o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            tk = tn; tn = tnn; q4 = qn;
         }
     }
 }

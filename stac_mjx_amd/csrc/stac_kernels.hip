@@ -813,12 +813,25 @@ void q_phase_kernel(const QArgs a_in) {
             const int co = k < 3 ? k : kXq + k - 3;
             const float *src = CBx + H.c_sw + co;
             float acc = 0.f;
-            int i = rr.lo;
-            for (; i + 4 <= rr.hi; i += 4) {  // four in flight per LDS round trip
-                const float v0 = src[kXf * i], v1 = src[kXf * (i + 1)], v2 = src[kXf * (i + 2)], v3 = src[kXf * (i + 3)];
-                acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
+            if constexpr (SPEC != 0) {
+                // (latency kernels: a lone wavefront waits out every LDS round trip, so eight sites per trip and no remainder loop --
+                //  the sites behind the range's end are read again at its last site and their additions dropped: the same sum)
+                const int last = rr.hi - 1;
+                for (int i = rr.lo; i < rr.hi; i += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[kXf * min(i + u, last)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = i + u <= last ? acc + v[u] : acc;
+                }
+            } else {
+                int i = rr.lo;
+                for (; i + 4 <= rr.hi; i += 4) {  // four in flight per LDS round trip
+                    const float v0 = src[kXf * i], v1 = src[kXf * (i + 1)], v2 = src[kXf * (i + 2)], v3 = src[kXf * (i + 3)];
+                    acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
+                }
+                for (; i < rr.hi; ++i) acc = acc + src[kXf * i];
             }
-            for (; i < rr.hi; ++i) acc = acc + src[kXf * i];
             CBx[H.c_rw + kXf * r + co] = acc;
         };
         // (B) one joint: its range's wrench, then the joint formulas; crefx = the root position the moments refer to
@@ -875,7 +888,7 @@ void q_phase_kernel(const QArgs a_in) {
         // The gradient of a free joint at qpos 0 .. 6 (active joint 0; QArgs::root_free / free0p), component lg on lane lg
         // < 7: the formulas of joint_gradient's free branch -- same operations, same order per component -- but the four
         // divisions side by side instead of one lane doing all seven components while the others wait.
-        auto free0_gradient = [&](float *CBx, const V3 crefx, const float *rw, const int qord) -> float {
+        auto free0_gradient = [&](float *CBx, const V3 crefx, const float *rw, const int qord, const int lg) -> float {  // (lg: the component)
             const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
             const V3 anchor = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_ja);
             const V3 tau = sub3(T0, cross3(sub3(anchor, crefx), Fs));
@@ -910,7 +923,7 @@ void q_phase_kernel(const QArgs a_in) {
             wave_sync();
             PROF_TICK(5);  // range sums
             if (a.free0p) {
-                const float gv = free0_gradient(CB, cref, CB + (LEAN ? H.c3_rw0 : H.c_rw + kXf * rid0), a.free0p - 1);
+                const float gv = free0_gradient(CB, cref, CB + (LEAN ? H.c3_rw0 : H.c_rw + kXf * rid0), a.free0p - 1, lg);
                 if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
             } else {
                 for (int j = lg; j < a.n_root_joints; j += G) joint_gradient(j, CB, cref, gg);
@@ -969,7 +982,7 @@ void q_phase_kernel(const QArgs a_in) {
                 }
             }
             if (a.free0p) {  // the free root joint: one component per lane, its four divisions side by side
-                const float gv = free0_gradient(CB, cref, CB + H.c_rw + kXf * __builtin_bit_cast(int, jrec[11]), a.free0p - 1);
+                const float gv = free0_gradient(CB, cref, CB + H.c_rw + kXf * __builtin_bit_cast(int, jrec[11]), a.free0p - 1, lg);
                 if (lg < 7 && (mbits & 1u)) gnew[0] = gv;
             }
             wave_sync();
@@ -1195,6 +1208,9 @@ void q_phase_kernel(const QArgs a_in) {
                         if (mine) { for (int t = (SOLO ? 0 : 6) + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
                         else if (lane < 6) range_task(lane, CBx);
                         wave_sync();
+#if defined(STAC_PROFILE) && defined(STAC_PROF_GRAD)  // (diagnostic: the range sums of the latency kernels' gradient pass charged to stamp 9)
+                        PROF_TICK(9);
+#endif
                         for (int j = lane; j < H.naj; j += 64) {
                             const bool on_longest = __builtin_bit_cast(int, jrec[12 * j + 11]) == 0;
                             if (SOLO || on_longest != mine) joint_gradient(j, CBx, crefx, gx);
