@@ -97,7 +97,7 @@ struct stac_model {
     int n_mlev_root = 0;        // micro-levels of the root-pass program currently in the blob (0 = none)
     int n_run_root = 0;         // of which the leading ones have work (n_mlev_root is padded to an even count)
     PlanHeader h3{};            // h with the chain layout of a lean launch (split kinematics, PlanHeader::fk3); valid when h.fk3
-    int fk3r[5] = {0, 0, 0, 0, 0};  // the pruned FK3 program currently in the blob: n1, n2, n3, m1, m3 (n3 = 0: none)
+    int fk3r[3] = {0, 0, 0};  // the pruned FK3 program currently in the blob: n1, n2, n3 (n3 = 0: none)
     std::vector<float> h_bpos;  // body_pos of the active bodies, by slot
     int32_t *d_lm_tab = nullptr;
     size_t lm_tab_words = 0;
@@ -348,7 +348,6 @@ static std::vector<int32_t> build_fk_program(const stac_model *m, const char *ne
 struct Fk3Program {
     std::vector<int32_t> words;   // T1 [16 (cap1 + 2)] (cap1 / 2 + 3 records of 24 words), T2 [cap2][4], T3 [cap3 * 4] (cap3 + 12 used), site words [K], joint words [naj]
     int n1 = 0, n2 = 0, n3 = 0;
-    uint32_t m1 = 0, m3 = 0;
 };
 struct Fk3Op { int prev; int height; int t = -1, pp = -1; bool restart = false; };
 // B, D: an operation may restart only in a step t with t % B == 0, and only from a predecessor finished in a step <= t - D (the
@@ -488,7 +487,7 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
     auto pbw = [&](int op) { return h3.c3_pb + 3 * (op < 0 ? root_slot : o3[op].t * 4 + o3[op].pp); };
     auto qbw = [&](int node) { return h3.c3_qb + 4 * node; };
     if (h3.stride3 >= 65536) return false;
-    out.n1 = std::max(n1, 0); out.n2 = n2; out.n3 = n3; out.m1 = out.m3 = 0;
+    out.n1 = std::max(n1, 0); out.n2 = n2; out.n3 = n3;
     // T1, blocks of two steps, 24 words per record: [24 r + 4 pp] = {ql word of step 2 r, of step 2 r + 1, out word of step 2 r - 2, of
     // 2 r - 1}, [24 r + 16 + 2 pp] = {restart entry of block r - 1, of block r} -- record r + 1 is what block r works from (its out words,
     // its restart flag, the next block's ql and restart words), record 0 the prologue.  A restart entry: the word of the quaternion the
@@ -838,16 +837,16 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                 ok = build_fk3_program(m, g, nullptr, g.fk3_cap1, g.fk3_cap2, g.fk3_cap3, full);
                 if (ok) {
                     g.fk3 = 1;
-                    g.fk3_n1 = full.n1; g.fk3_n2 = full.n2; g.fk3_n3 = full.n3; g.fk3_m1 = (int32_t)full.m1; g.fk3_m3 = (int32_t)full.m3;
+                    g.fk3_n1 = full.n1; g.fk3_n2 = full.n2; g.fk3_n3 = full.n3;
                     g.off3_prog = put_raw(full.words.data(), full.words.size());
                     g.off3_site = g.off3_prog + 16 * (g.fk3_cap1 + 2) + 4 * g.fk3_cap2 + 4 * g.fk3_cap3;
                     std::vector<int32_t> blank3(full.words.size(), 0);
                     g.off3_root = put_raw(blank3.data(), blank3.size());
                     // what both layouts share
-                    const int32_t keep[] = {g.fk3, g.off3_site, g.off3_prog, g.off3_root, g.fk3_n1, g.fk3_n2, g.fk3_n3, g.fk3_m1, g.fk3_m3,
+                    const int32_t keep[] = {g.fk3, g.off3_site, g.off3_prog, g.off3_root, g.fk3_n1, g.fk3_n2, g.fk3_n3,
                                             g.fk3_cap1, g.fk3_cap2, g.fk3_cap3};
                     h.fk3 = keep[0]; h.off3_site = keep[1]; h.off3_prog = keep[2]; h.off3_root = keep[3]; h.fk3_n1 = keep[4]; h.fk3_n2 = keep[5];
-                    h.fk3_n3 = keep[6]; h.fk3_m1 = keep[7]; h.fk3_m3 = keep[8]; h.fk3_cap1 = keep[9]; h.fk3_cap2 = keep[10]; h.fk3_cap3 = keep[11];
+                    h.fk3_n3 = keep[6]; h.fk3_cap1 = keep[7]; h.fk3_cap2 = keep[8]; h.fk3_cap3 = keep[9];
                     h.c3_ql = g.c3_ql; h.c3_qb = g.c3_qb; h.c3_pb = g.c3_pb; h.c3_rw0 = g.c3_rw0; h.stride3 = g.stride3;
                     m->h3 = g;
                 }
@@ -1682,7 +1681,7 @@ static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enabl
             int32_t *d3 = reinterpret_cast<int32_t *>(m->blob_host.data()) + h.off3_root;
             std::memcpy(d3, rp.words.data(), rp.words.size() * 4);
             HIP_TRY(hipMemcpyAsync(m->d_blob + h.off3_root, d3, rp.words.size() * 4, hipMemcpyHostToDevice, s));
-            m->fk3r[0] = rp.n1; m->fk3r[1] = rp.n2; m->fk3r[2] = rp.n3; m->fk3r[3] = (int)rp.m1; m->fk3r[4] = (int)rp.m3;
+            m->fk3r[0] = rp.n1; m->fk3r[1] = rp.n2; m->fk3r[2] = rp.n3;
         }
     }
     return STAC_OK;
@@ -1786,7 +1785,7 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
     a.n_run_root = do_root_opt ? m->n_run_root : 0;
     a.n_root_joints = n_root_joints;
-    if (do_root_opt && m->h.fk3) { a.fk3r_n1 = m->fk3r[0]; a.fk3r_n2 = m->fk3r[1]; a.fk3r_n3 = m->fk3r[2]; a.fk3r_m1 = m->fk3r[3]; a.fk3r_m3 = m->fk3r[4]; }
+    if (do_root_opt && m->h.fk3) { a.fk3r_n1 = m->fk3r[0]; a.fk3r_n2 = m->fk3r[1]; a.fk3r_n3 = m->fk3r[2]; }
     // Root fast trips (QArgs::root_fast): the root coordinates are the first root_dims (<= 8: register 0 of every lane
     // group of 8 or more lanes) and belong to leading joints that share ONE subtree range, whose weighted sites fit a 64-bit mask
     if (do_root_opt && m->n_mlev_root > 0 && n_root_joints >= 1 && n_root_joints < m->h.naj && root_dims <= 8 && K <= 64 && !m->dbg.nofast) {

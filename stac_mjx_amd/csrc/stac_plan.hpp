@@ -180,16 +180,15 @@ struct PlanHeader {
     int32_t fk3;           // 1: the tables below exist (else the lean kernels are not used for this model)
     int32_t off3_site;     // [K] per site: word of its body's position | word of its body's quaternion << 16 (chain region), full program;
                            // then [naj] per joint: word of its anchor | word of its pre-joint quaternion << 16
-    int32_t off3_prog;     // full program: T1 [(cap1 + 2) * 4][4] rows {ql word of the NEXT step, out word, restart word | -1, -} (row 0: a
-                           // prologue), T2 [cap2][4] {v.x, v.y, v.z, q word | out word << 16}, T3 [cap3 * 4] restart word | -1, then the
-                           // site and joint words
+    int32_t off3_prog;     // full program: T1 [16 (cap1 + 2)] = cap1 / 2 + 3 records of 24 words, a record per block of two steps (layout:
+                           // build_fk3_program, stac_abi.hip), T2 [cap2][4] {v.x, v.y, v.z, q word | out word << 16}, T3 [cap3 * 4]: per block of
+                           // four steps and position the restart entry (word of the value, or bit 31 | a valid word), then the site and joint words
     int32_t off3_root;     // same layout: the pruned program of the root passes (filled per call)
-    int32_t fk3_n1, fk3_n2, fk3_n3;   // steps of P1, tasks of P2 (padded to a multiple of 32 with no-ops), steps of P3: full program
-    int32_t fk3_m1, fk3_m3;           // bit t: some position restarts from another position's result in step t of P1 / P3
+    int32_t fk3_n1, fk3_n2, fk3_n3;   // steps of P1 (even), tasks of P2 (padded to a multiple of 32 with no-ops), steps of P3 (a multiple of 4): full program
     int32_t fk3_cap1, fk3_cap2, fk3_cap3;  // capacity of either program area (steps / tasks): where T2, T3 and the site words start
     int32_t c3_ql;         // [naj * 4] joint-local quaternions (w, x, y, z) by active joint; the range sums of a full trip alias it
     int32_t c3_qb;         // [naj * 4] quaternion AFTER every active joint (w, x, y, z); entry 0 = the free root's
-    int32_t c3_pb;         // [(cap3 * 4 + 2) * 3] position slots by (step, position) of P3; then the root position, then a sink
+    int32_t c3_pb;         // [(cap3 * 4 + 4) * 3] position slots by (step, position) of P3; then the root position, a sink, slack
     int32_t c3_rw0;        // [kXf] range sum of the root joint in a root fast trip (which keeps c3_ql intact)
     int32_t stride3;       // chain stride of a lean launch (odd)
 };
@@ -235,7 +234,7 @@ struct QArgs {
     int32_t n_mlev_root;    // micro-levels of the root-pass FK program at h.off_fkroot; 0 = none (never prune)
     int32_t n_run_root;     // steps of that program that have work (<= n_mlev_root, which is padded to an even count)
     int32_t n_root_joints;  // leading active joints that carry the root passes' coordinates
-    int32_t fk3r_n1, fk3r_n2, fk3r_n3, fk3r_m1, fk3r_m3;  // the pruned FK3 program at h.off3_root (PlanHeader::fk3_*): steps, tasks, restart masks
+    int32_t fk3r_n1, fk3r_n2, fk3r_n3;  // the pruned FK3 program at h.off3_root (PlanHeader::fk3_*): steps of P1, tasks of P2, steps of P3
     // Root fast trips (throughput kernels).  While every live chain of a wavefront is in a root solve, only the first
     // root_fast coordinates move: the joint-local quaternions of all other joints, computed once, stay valid (the root
     // program parks their anchor / pre-joint entries in the sink), the gradient is the root joint's alone and its subtree
