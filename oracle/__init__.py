@@ -219,6 +219,12 @@ class Oracle:
                               _p(lb, _f32p), _p(ub, _f32p), _p(out, _f32p), C.byref(st))
         return out, st.as_dict()
 
+    def lm_jac_check(self, q, kp):
+        """max |J^T f - grad| of the LM solver's Jacobian columns against the analytic gradient (stac_oracle.c::orc_lm_jac_check)."""
+        q, kp = _f32(q), _f32(kp)
+        self.lib.orc_lm_jac_check.restype = C.c_double
+        return float(self.lib.orc_lm_jac_check(C.byref(self.m), _p(q, _f32p), _p(kp, _f32p)))
+
     def ik_clips_lm(self, kp, lb, ub, part_masks, trunk_kps, root_kp_idx, root_dims=7, do_root_opt=True, q_init=None,
                     nthreads=0, want_bodies=True, maxiter=40, lambda0=1e-2):
         kp, lb, ub = _f32(kp), _f32(lb), _f32(ub)

@@ -584,6 +584,21 @@ static void lm_free(lm_ws_t *l) {
 
 /* One column of the 3 x nd site Jacobian at the pose of the last fk_ws (w->qf normalised, anchors, axes, jnorm filled):
  * stac_lm.hip, jac_col, operation for operation. */
+/* raw quaternion (s,u), q^ = q/|q|, d = the rotated vector: dx/ds = -2 (u^ x d)/|q|, dx/du_j = 2 (s^ (e_j x d) - (e_j x u^) x d)/|q| */
+static void lm_quat_col(const real *qh, real n, int c4, const real *d, real *col) {
+    const real dn = n + (n == R(0) ? R(1e-6) : R(0));
+    if (c4 == 0) {
+        cross3(qh + 1, d, col);
+        for (int t = 0; t < 3; ++t) col[t] = (R(-2) * col[t]) / dn;
+    } else {
+        real e[3] = {R(0), R(0), R(0)}, exd[3], exu[3], t2[3];
+        e[c4 - 1] = R(1);
+        cross3(e, d, exd);
+        cross3(e, qh + 1, exu);
+        cross3(exu, d, t2);
+        for (int t = 0; t < 3; ++t) col[t] = (R(2) * (qh[0] * exd[t] - t2[t])) / dn;
+    }
+}
 static void lm_jac_col(const orc_model *m, const ws_t *w, int j, int comp, const real *sx, real *col) {
     const real *anchor = w->xanchor + 3 * j, *axis = w->xaxis + 3 * j;
     real dvec[3];
@@ -593,24 +608,17 @@ static void lm_jac_col(const orc_model *m, const ws_t *w, int j, int comp, const
     case ORC_JNT_SLIDE: col[0] = axis[0]; col[1] = axis[1]; col[2] = axis[2]; break;
     case ORC_JNT_FREE:
         if (comp < 3) { col[0] = comp == 0; col[1] = comp == 1; col[2] = comp == 2; }
-        else {
-            /* raw quaternion (s,u), q^ = q/|q|: dx/ds = -2 (u^ x d)/|q|, dx/du_j = 2 (s^ (e_j x d) - (e_j x u^) x d)/|q| */
-            const real *qh = w->qf + m->jnt_qposadr[j] + 3;
-            const real n = w->jnorm[j], dn = n + (n == R(0) ? R(1e-6) : R(0));
-            if (comp == 3) {
-                cross3(qh + 1, dvec, col);
-                for (int t = 0; t < 3; ++t) col[t] = (R(-2) * col[t]) / dn;
-            } else {
-                real e[3] = {R(0), R(0), R(0)}, exd[3], exu[3], t2[3];
-                e[comp - 4] = R(1);
-                cross3(e, dvec, exd);
-                cross3(e, qh + 1, exu);
-                cross3(exu, dvec, t2);
-                for (int t = 0; t < 3; ++t) col[t] = (R(2) * (qh[0] * exd[t] - t2[t])) / dn;
-            }
-        }
+        else lm_quat_col(w->qf + m->jnt_qposadr[j] + 3, w->jnorm[j], comp - 3, dvec, col);
         break;
-    default: col[0] = col[1] = col[2] = R(0); break; /* ball: unsupported */
+    case ORC_JNT_BALL: { /* in the frame the ball rotation is applied in, and back (as the gradient's torque) */
+        const real *pre = w->jprequat + 4 * j;
+        const real qc[4] = {pre[0], -pre[1], -pre[2], -pre[3]};
+        real dl[3], cl[3];
+        rotate(dvec, qc, dl);
+        lm_quat_col(w->qf + m->jnt_qposadr[j], w->jnorm[j], comp, dl, cl);
+        rotate(cl, pre, col);
+    } break;
+    default: col[0] = col[1] = col[2] = R(0); break;
     }
 }
 
@@ -643,7 +651,7 @@ static void q_opt_lm_ws(const orc_model *m, ws_t *w, lm_ws_t *l, const orc_lm_pa
     for (int j = 0; j < m->njnt; ++j) {
         const int b = m->jnt_bodyid[j], a = m->jnt_qposadr[j];
         const int dims = m->jnt_type[j] == ORC_JNT_FREE ? 7 : (m->jnt_type[j] == ORC_JNT_BALL ? 4 : 1);
-        if (w->bhi[b] <= w->blo[b] || m->jnt_type[j] == ORC_JNT_BALL) continue;
+        if (w->bhi[b] <= w->blo[b]) continue;
         for (int c = 0; c < dims; ++c)
             if (qs_to_opt[a + c]) { l->dof[l->nd] = a + c; l->dof_jnt[l->nd] = j; l->nd++; }
     }
@@ -696,13 +704,13 @@ static void q_opt_lm_ws(const orc_model *m, ws_t *w, lm_ws_t *l, const orc_lm_pa
             const real xe = w->qf[e]; /* the accepted point as staged (root quaternion normalised) */
             l->frozen[b2] = (xe <= w->lb[e] && l->b[b2] < R(0)) || (xe >= w->ub[e] && l->b[b2] > R(0));
         }
-        /* gauge of the raw root quaternion: its length does not change the pose; make that direction stiff */
+        /* gauge of a raw quaternion (the free root's, a ball joint's): its length does not change the pose; make that direction stiff */
         for (int b2 = 0; b2 + 3 < nd; ++b2) {
-            const int j = l->dof_jnt[b2];
-            if (m->jnt_type[j] != ORC_JNT_FREE || l->dof[b2] != m->jnt_qposadr[j] + 3 || l->dof_jnt[b2 + 3] != j ||
-                l->dof[b2 + 3] != m->jnt_qposadr[j] + 6)
+            const int j = l->dof_jnt[b2], ty = m->jnt_type[j];
+            const int qa = m->jnt_qposadr[j] + (ty == ORC_JNT_FREE ? 3 : 0);
+            if ((ty != ORC_JNT_FREE && ty != ORC_JNT_BALL) || l->dof[b2] != qa || l->dof_jnt[b2 + 3] != j || l->dof[b2 + 3] != qa + 3)
                 continue;
-            const real *qh = w->qf + m->jnt_qposadr[j] + 3;
+            const real *qh = w->qf + qa;
             for (int c = 0; c < 4; ++c)
                 for (int e = 0; e <= c; ++e) l->A[(size_t)(b2 + c) * nd + b2 + e] += qh[c] * qh[e];
         }
@@ -799,6 +807,40 @@ void orc_q_opt_lm(const orc_model *m, const orc_lm_params *p, const float *kp, c
     for (int i = 0; i < m->nq; ++i) params_out[i] = (float)w->x[i];
     lm_free(l);
     ws_free(w);
+}
+
+/* Self-check of the LM solver's Jacobian columns (tests/test_oracle.py): with f_k = -2 w_k (kp_k - x_k) the analytic gradient of
+ * the loss is grad[a] = sum over the sites of dot3(dx_k/dq_a, f_k) for every coordinate a.  Returns the largest difference between
+ * that sum over lm_jac_col's columns and q_loss_ws's gradient over all coordinates (hinge, slide, free and ball joints). */
+double orc_lm_jac_check(const orc_model *m, const float *q, const float *kp) {
+    ws_t *w = ws_new(m);
+    const int nq = m->nq, K = m->nsite;
+    uint8_t *ones = (uint8_t *)malloc((size_t)(nq > 3 * K ? nq : 3 * K));
+    memset(ones, 1, (size_t)(nq > 3 * K ? nq : 3 * K));
+    real *x = (real *)malloc(sizeof(real) * (size_t)nq), *g = (real *)malloc(sizeof(real) * (size_t)nq);
+    for (int i = 0; i < nq; ++i) { x[i] = R(q[i]); w->q0[i] = R(q[i]); }
+    for (int i = 0; i < 3 * K; ++i) w->kp[i] = R(kp[i]);
+    (void)q_loss_ws(m, w, x, w->kp, ones, ones, w->q0, g);
+    double worst = 0.0;
+    for (int j = 0; j < m->njnt; ++j) {
+        const int dims = m->jnt_type[j] == ORC_JNT_FREE ? 7 : (m->jnt_type[j] == ORC_JNT_BALL ? 4 : 1);
+        for (int c = 0; c < dims; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) {
+                int below = 0;
+                for (int b = m->site_bodyid[k]; b > 0 && !below; b = m->body_parentid[b]) below = b == m->jnt_bodyid[j];
+                if (!below) continue;
+                real col[3];
+                lm_jac_col(m, w, j, c, w->sx + 3 * k, col);
+                for (int t = 0; t < 3; ++t) s += (double)col[t] * (double)(R(-2) * (w->kp[3 * k + t] - w->sx[3 * k + t]));
+            }
+            const double d = fabs(s - (double)g[m->jnt_qposadr[j] + c]);
+            if (d > worst) worst = d;
+        }
+    }
+    free(x); free(g); free(ones);
+    ws_free(w);
+    return worst;
 }
 
 /* ---- phase drivers (compute_stac.py) -------------------------------------------------------- */

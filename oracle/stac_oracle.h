@@ -100,12 +100,13 @@ void orc_q_opt(const orc_model *m, const orc_pg_params *p, const float *kp,
  * (stac_mjx_amd/csrc/stac_lm.hip), so that the GPU tests compare the two bit for bit.  Per iteration: the loss as the sum
  * of the per-site terms four at a time in site order; Gauss-Newton entries A[b][a] = sum over the DFS-ordered sites below
  * coordinate b of dot3(J_b, J_a) for the coordinates a on b's root path (others are structurally zero), b = -g / 2, a gauge
- * term on the raw root quaternion; multiplicative damping fma(A_ii, lambda, A_ii) + 1e-9, bound-active coordinates frozen;
+ * term on every raw quaternion (free root, ball joints); multiplicative damping fma(A_ii, lambda, A_ii) + 1e-9, bound-active coordinates frozen;
  * Featherstone's L^T D L on the root paths (pivots in decreasing qpos order: no fill-in), y = L^-T b on the fly,
  * z = D^-1 y, d = L^-1 z ancestors first; step clipped to the box, accepted if the loss decreases (lambda /= 2) else
  * lambda *= 4 (at most 8 times in a row; a matrix that is not positive definite counts as a rejected evaluation of the
  * point itself).  Stops on the same residual as the PG solver (||clip(x - grad) - x|| <= tol) or after maxiter accepted
- * steps.  Ball joints are not supported. */
+ * steps.  A ball joint's four raw quaternion components are coordinates like the free root's (columns in the frame the ball
+ * rotation is applied in, the same gauge term). */
 typedef struct {
     float tol;       /* same stopping residual as the PG solver */
     int32_t maxiter; /* accepted steps, e.g. 40 */
@@ -115,6 +116,9 @@ typedef struct {
 void orc_q_opt_lm(const orc_model *m, const orc_lm_params *p, const float *kp, const uint8_t *qs_to_opt,
                   const uint8_t *kps_to_opt, const float *q0, const float *lb, const float *ub,
                   float *params_out, orc_pg_state *state_out);
+
+/* Self-check of the LM Jacobian columns against the analytic gradient (all coordinates, all sites weighted 1): max |J^T f - grad|. */
+double orc_lm_jac_check(const orc_model *m, const float *q, const float *kp);
 
 /* orc_ik_clips with the LM solver in place of every PG solve (same sequencing, masks and replace_qs). */
 void orc_ik_clips_lm(const orc_model *m, const orc_lm_params *p, const float *kp, int32_t C, int32_t F,

@@ -1444,7 +1444,6 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
 static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]*/, int nkinds, float lambda0, hipStream_t s) {
     const PlanHeader &h = m->h;
     const int naj = h.naj, nab = h.nab;
-    if (h.has_ball) return fail(STAC_ERR_INVALID, "STAC_SOLVER_LM does not support ball joints");
     std::vector<int32_t> tab((size_t)nkinds * kLmKindWords, 0), hot, cold;
     int n_max = 0, maxpd_all = 1, npk_max = 4;
     auto is_anc_or_self = [&](int sa, int sb) {  // slot sa ancestor-or-equal of slot sb
@@ -1457,7 +1456,7 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
         std::vector<Dof> D;
         for (int j = 0; j < naj; ++j) {
             if (m->h_aj_shi[j] <= m->h_aj_slo[j]) continue;  // no fit site below this joint
-            const int dims = m->h_aj_type[j] == STAC_JNT_FREE ? 7 : 1;
+            const int dims = m->h_aj_type[j] == STAC_JNT_FREE ? 7 : (m->h_aj_type[j] == STAC_JNT_BALL ? 4 : 1);
             for (int c = 0; c < dims; ++c)
                 if (mask[m->h_aj_qadr[j] + c]) D.push_back({m->h_aj_qadr[j] + c, j, c, 0});
         }
@@ -1489,19 +1488,24 @@ static int build_lm_tables(stac_model *m, const uint8_t *masks /*[nkinds, nqpad]
         if (maxpd > 255) return fail(STAC_ERR_CAPACITY, "kinematic path too deep for the LM solver");
         std::stable_sort(E.begin(), E.end(), [](const Ent &x, const Ent &y) { return x.len > y.len; });
         for (const Ent &e : E) { ents.push_back(e.row); ents.push_back(e.col); ents.push_back(e.pds); ents.push_back(e.range); }
-        int quat0 = -1;
-        for (int b = 0; b + 3 < nd; ++b)
-            if (m->h_aj_type[D[b].joint] == STAC_JNT_FREE && D[b].comp == 3 && D[b + 3].joint == D[b].joint && D[b + 3].comp == 6)
-                quat0 = b;
+        // raw quaternions (the free root's, every ball joint's) of which all four components are optimised: index of their first dof
+        std::vector<int32_t> quats;
+        for (int b = 0; b + 3 < nd; ++b) {
+            const int ty = m->h_aj_type[D[b].joint], c0 = ty == STAC_JNT_FREE ? 3 : 0;
+            if ((ty == STAC_JNT_FREE || ty == STAC_JNT_BALL) && D[b].comp == c0 && D[b + 3].joint == D[b].joint && D[b + 3].comp == c0 + 3)
+                quats.push_back(b);
+        }
         const size_t kho = (size_t)kind * kLmKindWords;
         tab[kho + 0] = nd; tab[kho + 1] = (int)E.size(); tab[kho + 2] = (int)items.size() / 4; tab[kho + 3] = maxpd;
-        tab[kho + 7] = quat0;
+        tab[kho + 7] = (int)quats.size();
         // hot section (LDS): dof records + path table; cold section (global): entries + items
         tab[kho + 4] = (int)hot.size();
         for (const Dof &d : D) { hot.push_back(d.qadr); hot.push_back(d.joint); hot.push_back(d.comp); hot.push_back(d.pd); }
         tab[kho + 8] = (int)hot.size();
         for (int b = 0; b < nd; ++b)
             for (int pi = 0; pi < maxpd; ++pi) hot.push_back(pi < (int)paths[b].size() ? paths[b][pi] : -1);
+        tab[kho + 9] = (int)hot.size();
+        hot.insert(hot.end(), quats.begin(), quats.end());
         while (hot.size() & 3) hot.push_back(0);
         tab[kho + 5] = (int)cold.size();
         cold.insert(cold.end(), ents.begin(), ents.end());

@@ -27,23 +27,31 @@ enum : int { LM_EVAL_X = 0, LM_TRIAL = 1, LM_DONE = 3 };
 struct DofGeom {
     int ty, comp;
     V3 anchor, axis;  // joint anchor and world axis (hinge / slide)
-    Q4 qh;            // normalised root quaternion (free joint)
+    Q4 qh;            // normalised raw quaternion (free / ball joint)
+    Q4 pre;           // ball joint: the quaternion in front of the joint (its rotation is applied in that frame)
     float dn;         // |q| (+1e-6 if 0)
 };
+// raw quaternion (s, u), q^ = q / |q|, d = the rotated vector: dx/ds = -2 (u^ x d) / |q|, dx/du_j = 2 (s^ (e_j x d) - (e_j x u^) x d) / |q|
+__device__ __forceinline__ V3 quat_col(const Q4 qh, const float dn, const int c4, const V3 d) {
+    const V3 u = {qh.x, qh.y, qh.z};
+    if (c4 == 0) {
+        const V3 c = cross3(u, d);
+        return {(-2.0f * c.x) / dn, (-2.0f * c.y) / dn, (-2.0f * c.z) / dn};
+    }
+    const V3 e = {c4 == 1 ? 1.f : 0.f, c4 == 2 ? 1.f : 0.f, c4 == 3 ? 1.f : 0.f};
+    const V3 exd = cross3(e, d), t2 = cross3(cross3(e, u), d);
+    return {(2.0f * (qh.w * exd.x - t2.x)) / dn, (2.0f * (qh.w * exd.y - t2.y)) / dn, (2.0f * (qh.w * exd.z - t2.z)) / dn};
+}
 __device__ __forceinline__ V3 jac_col(const DofGeom &g, V3 sx) {
     const V3 d = sub3(sx, g.anchor);
     if (g.ty == JHINGE) return cross3(g.axis, d);
     if (g.ty == JSLIDE) return g.axis;
-    if (g.comp < 3) return {g.comp == 0 ? 1.f : 0.f, g.comp == 1 ? 1.f : 0.f, g.comp == 2 ? 1.f : 0.f};
-    const V3 u = {g.qh.x, g.qh.y, g.qh.z};
-    if (g.comp == 3) {
-        const V3 c = cross3(u, d);
-        return {(-2.0f * c.x) / g.dn, (-2.0f * c.y) / g.dn, (-2.0f * c.z) / g.dn};
+    if (g.ty == JBALL) {  // in the frame the ball rotation is applied in, and back
+        const V3 dl = rotate(d, Q4{g.pre.w, -g.pre.x, -g.pre.y, -g.pre.z});
+        return rotate(quat_col(g.qh, g.dn, g.comp, dl), g.pre);
     }
-    const V3 e = {g.comp == 4 ? 1.f : 0.f, g.comp == 5 ? 1.f : 0.f, g.comp == 6 ? 1.f : 0.f};
-    const V3 exd = cross3(e, d), t2 = cross3(cross3(e, u), d);
-    return {(2.0f * (g.qh.w * exd.x - t2.x)) / g.dn, (2.0f * (g.qh.w * exd.y - t2.y)) / g.dn,
-            (2.0f * (g.qh.w * exd.z - t2.z)) / g.dn};
+    if (g.comp < 3) return {g.comp == 0 ? 1.f : 0.f, g.comp == 1 ? 1.f : 0.f, g.comp == 2 ? 1.f : 0.f};
+    return quat_col(g.qh, g.dn, g.comp - 3, d);
 }
 
 template <int G, int NQR, int WPE>
@@ -240,17 +248,24 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                 const V3 axis = rotate(V3{ja4.x, ja4.y, ja4.z}, prequat);
                 st3(ja + kXf * j + kXq, axis);
                 gg[ad] = ty == JHINGE ? dot3(axis, tau) : dot3(axis, Fs);
-            } else if (ty == JFREE) {
-                st3(gg + ad, Fs);
-                const Q4 qh = ld4(qe + ad + 3);
+            } else {  // free / ball (the PG kernel's formulas: stac_kernels.hip, joint_gradient)
+                int qa = ad;
+                V3 tl = tau;
+                if (ty == JFREE) {
+                    st3(gg + ad, Fs);
+                    qa = ad + 3;
+                } else {
+                    tl = rotate(tau, Q4{prequat.w, -prequat.x, -prequat.y, -prequat.z});  // in the frame the ball rotation is applied in
+                }
+                const Q4 qh = ld4(qe + qa);
                 const V3 u = {qh.x, qh.y, qh.z};
-                const V3 uxt = cross3(u, tau);
+                const V3 uxt = cross3(u, tl);
                 const float n = jn[__builtin_bit_cast(int, lds4(jr + 4).w)];  // by quaternion ordinal
                 const float dn = n + (n == 0.0f ? 1e-6f : 0.0f);
-                gg[ad + 3] = (-2.0f * dot3(tau, u)) / dn;
-                gg[ad + 4] = (2.0f * FMA(qh.w, tau.x, -uxt.x)) / dn;
-                gg[ad + 5] = (2.0f * FMA(qh.w, tau.y, -uxt.y)) / dn;
-                gg[ad + 6] = (2.0f * FMA(qh.w, tau.z, -uxt.z)) / dn;
+                gg[qa] = (-2.0f * dot3(tl, u)) / dn;
+                gg[qa + 1] = (2.0f * FMA(qh.w, tl.x, -uxt.x)) / dn;
+                gg[qa + 2] = (2.0f * FMA(qh.w, tl.y, -uxt.y)) / dn;
+                gg[qa + 3] = (2.0f * FMA(qh.w, tl.z, -uxt.z)) / dn;
             }
         }
         wave_sync();
@@ -318,10 +333,12 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                     g2.anchor = ld_tpos(ja + kXf * dr.y);
                     g2.axis = ld3(ja + kXf * dr.y + kXq);
                     g2.qh = Q4{1.f, 0.f, 0.f, 0.f};
+                    g2.pre = Q4{1.f, 0.f, 0.f, 0.f};
                     g2.dn = 1.0f;
-                    if (g2.ty == JFREE) {
+                    if (g2.ty == JFREE || g2.ty == JBALL) {
                         const int ad = reinterpret_cast<const int *>(jr)[1];
-                        g2.qh = ld4(qe + ad + 3);
+                        g2.qh = ld4(qe + (g2.ty == JFREE ? ad + 3 : ad));
+                        if (g2.ty == JBALL) g2.pre = ld_tquat(ja + kXf * dr.y);  // (a ball's entry keeps its pre-joint quaternion: no world axis)
                         const float nn = jn[__builtin_bit_cast(int, lds4(jr + 4).w)];  // by quaternion ordinal
                         g2.dn = nn + (nn == 0.0f ? 1e-6f : 0.0f);
                     }
@@ -357,13 +374,17 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                 }
             }
             wave_sync();
-            if (need_system && kh.quat0 >= 0 && lg < 10) {
-                // gauge: the length of the raw root quaternion does not change the pose -- make that direction stiff
-                int c = 0, e = lg;
-                while (e > c) { e -= c + 1; ++c; }  // lg -> (c, e), e <= c < 4
-                // the four raw-quaternion dofs are consecutive on one root path: pd(quat0 + c) = pd(quat0) + c
-                const int ad = KT[kh.off_dof + 4 * kh.quat0], pd0 = KT[kh.off_dof + 4 * kh.quat0 + 3];
-                Ap[(kh.quat0 + c) * kh.maxpd + pd0 + e] += qe[ad + c] * qe[ad + e];
+            if (need_system) {
+                // gauge: the length of a raw quaternion (the free root's, a ball joint's) does not change the pose -- make that direction stiff
+                for (int idx = lg; idx < 10 * kh.nquat; idx += G) {
+                    const int qi = idx / 10;
+                    int c = 0, e = idx - 10 * qi;
+                    while (e > c) { e -= c + 1; ++c; }  // -> (c, e), e <= c < 4
+                    // the four raw-quaternion dofs are consecutive on one root path: pd(b0 + c) = pd(b0) + c
+                    const int b0 = KT[kh.off_quat + qi];
+                    const int ad = KT[kh.off_dof + 4 * b0], pd0 = KT[kh.off_dof + 4 * b0 + 3];
+                    Ap[(b0 + c) * kh.maxpd + pd0 + e] += qe[ad + c] * qe[ad + e];
+                }
             }
             wave_sync();
         }

@@ -278,10 +278,11 @@ struct LmKind {            // 12 words, at blob[kind * 12]
     int32_t off_dof;       // LmDof[nd]            -- offset inside the HOT section (staged in LDS)
     int32_t off_ent;       // LmEnt[ne], longest site range first   -- absolute, read from global memory
     int32_t off_item;      // LmItem[ni]                            -- absolute, read from global memory
-    int32_t quat0;         // index of the first raw root-quaternion dof when all four are optimised, else -1
+    int32_t nquat;         // raw quaternions (free root, ball joints) of which all four components are optimised
     int32_t off_anc;       // int32[nd * maxpd]: dof index at every position of the dof's root path (-1 beyond);
                            // offset inside the HOT section
-    int32_t pad0, pad1, pad2;
+    int32_t off_quat;      // int32[nquat]: index of each such quaternion's first dof (HOT section)
+    int32_t pad1, pad2;
 };
 constexpr int kLmKindWords = 12;
 struct LmDof { int32_t qadr, joint, comp, pd; };                 // qpos index, active joint, component, path depth

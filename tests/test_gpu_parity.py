@@ -640,6 +640,37 @@ def test_lm_q_phase_matches_oracle_lm_in_marker_space(rodent_setup, rodent_mocap
     assert it < 60, it
 
 
+@pytest.mark.parametrize("seed,free_root", [(0, True), (1, False), (2, True), (5, False)])
+def test_lm_ball_and_slide_models_bit_exact(seed, free_root):
+    """Round 5: ball joints in the LM solver (four raw quaternion coordinates per joint, columns in the frame the rotation is applied
+    in, the gauge term of every quaternion) -- HIP == the oracle's LM bit for bit on random trees with ball, slide and hinge joints."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+    from test_oracle import _ball_case
+
+    rng, t, lb, ub = _ball_case(seed, free_root)
+    assert (t.jnt_type == 1).sum() >= 3
+    orc = Oracle(t, tol=1e-4, maxiter=50)
+    C, F, K, nq = 9, 2, t.nsite, t.nq
+    q = np.tile(t.qpos0, (C * F, 1)) + rng.normal(0, 0.15, (C * F, nq)).astype(np.float32)
+    q = np.clip(q, np.where(np.isfinite(lb), lb, -3), np.where(np.isfinite(ub), ub, 3)).astype(np.float32)
+    kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32)
+    kp = (kp + rng.normal(0, 1e-3, kp.shape)).astype(np.float32).reshape(C, F, 3 * K)
+    part = (rng.random((2, nq)) < 0.4).astype(np.uint8)
+    trunk = (rng.random(K) < 0.6).astype(np.uint8)
+    trunk[0] = 1
+    ref = orc.ik_clips_lm(kp, lb, ub, part, trunk, 0, 7, do_root_opt=free_root, maxiter=15)
+    for lanes in (0, 64):
+        eng = Engine(t, lb, ub, tol=1e-4, solver="lm", lm_maxiter=15, lanes_per_chain=lanes)
+        res = eng.q_phase(kp, part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=free_root)
+        np.testing.assert_array_equal(_np(res["qpos"]).view(np.uint32), ref["qpos"].view(np.uint32))
+        np.testing.assert_array_equal(_np(res["frame_error"]).view(np.uint32), ref["frame_error"].view(np.uint32))
+        np.testing.assert_array_equal(_np(res["counters"]).astype(np.uint32), ref["counters"])
+        eng.close()
+    tgt = kp.reshape(C, F, K, 3)
+    assert np.linalg.norm(ref["marker_sites"].reshape(C, F, K, 3) - tgt, axis=-1).mean() < 5e-3
+
+
 def test_lm_chain_queue_same_as_static_assignment(rodent_setup, rodent_mocap, monkeypatch):
     """LM kernel with the chain queue forced (8 slots for 30 chains): which group ran which chain must not matter --
     identical outputs to the launch where every chain has its own slot."""

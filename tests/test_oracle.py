@@ -472,3 +472,54 @@ def test_pg_driver_equals_independent_transcription(orc, rodent_setup, rodent_mo
     for k in ("iter_num", "stepsize", "error", "t", "ls_evals"):
         assert st_c[k] == st_p[k], (k, st_c[k], st_p[k])
     assert st_c["iter_num"] > 3
+
+
+def _ball_case(seed, free_root):
+    """A random tree with ball, slide and hinge joints (the generator of the GPU fuzz tests), a pose and targets near it."""
+    from test_gpu_parity import _random_tables
+    from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE
+
+    rng = np.random.default_rng(seed)
+    t = _random_tables(rng, 24, free_root, p_slide=0.15, p_ball=0.3)
+    lb, ub = np.full(t.nq, -np.inf, np.float32), np.full(t.nq, np.inf, np.float32)
+    for j in range(t.njnt):
+        a, ty = int(t.jnt_qposadr[j]), int(t.jnt_type[j])
+        if ty == JNT_FREE: lb[a + 3:a + 7], ub[a + 3:a + 7] = -1, 1
+        elif ty == JNT_BALL: lb[a:a + 4], ub[a:a + 4] = -1, 1
+        else: lb[a], ub[a] = min(t.jnt_range[j, 0], 0.0), t.jnt_range[j, 1]
+    return rng, t, lb, ub
+
+
+@pytest.mark.parametrize("seed,free_root", [(0, True), (1, False), (2, True), (3, False)])
+def test_lm_jacobian_columns_agree_with_the_analytic_gradient(seed, free_root):
+    """Round 5 (ball joints in the LM solver): J^T f over lm_jac_col's columns == the gradient q_loss computes, for every coordinate
+    of hinge, slide, free and ball joints (a ball's columns: in the frame its rotation is applied in, and back)."""
+    rng, t, lb, ub = _ball_case(seed, free_root)
+    assert (t.jnt_type == 1).sum() >= 3
+    q = np.asarray(t.qpos0, np.float32) + 0.2 * rng.standard_normal(t.nq).astype(np.float32)
+    kp = (0.1 * rng.standard_normal(3 * t.nsite)).astype(np.float32)
+    assert Oracle(t, precision="f64").lm_jac_check(q, kp) < 1e-7   # (float inputs, double arithmetic)
+    assert Oracle(t).lm_jac_check(q, kp) < 5e-6
+
+
+@pytest.mark.parametrize("seed,free_root", [(0, True), (1, False)])
+def test_lm_with_ball_joints_converges_and_fits_at_least_as_well_as_pg(seed, free_root):
+    rng, t, lb, ub = _ball_case(seed, free_root)
+    orc = Oracle(t, tol=1e-4, maxiter=400)
+    n, K = 6, t.nsite
+    q = np.tile(t.qpos0, (n, 1)) + rng.normal(0, 0.15, (n, t.nq)).astype(np.float32)
+    q = np.clip(q, np.where(np.isfinite(lb), lb, -3), np.where(np.isfinite(ub), ub, 3)).astype(np.float32)
+    kp = np.stack([orc.fk(x.copy())["site_xpos"].reshape(-1) for x in q]).astype(np.float32).reshape(n, 1, 3 * K)
+    part = np.zeros((0, t.nq), np.uint8)
+    trunk = np.ones(K, np.uint8)
+    lm = orc.ik_clips_lm(kp, lb, ub, part, trunk, 0, 7, do_root_opt=free_root, want_bodies=False, maxiter=40)
+    pg = orc.ik_clips(kp, lb, ub, part, trunk, 0, 7, do_root_opt=free_root, want_bodies=False)
+    tgt = kp.reshape(n, 1, K, 3)
+    e_lm = np.linalg.norm(lm["marker_sites"] - tgt, axis=-1).mean()
+    e_pg = np.linalg.norm(pg["marker_sites"] - tgt, axis=-1).mean()
+    assert e_lm <= e_pg + 1e-5 and e_lm < 2e-3, (e_lm, e_pg)
+    ql = lm["qpos"][:, 0]
+    fin = np.isfinite(lb) & np.isfinite(ub)
+    assert (ql[:, fin] >= lb[fin] - 1e-6).all() and (ql[:, fin] <= ub[fin] + 1e-6).all()
+    # far fewer evaluations than the projected gradient needs
+    assert lm["counters"][..., 2].mean() < 0.25 * (pg["counters"][..., 1] + pg["counters"][..., 2]).mean()
