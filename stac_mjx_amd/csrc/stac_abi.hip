@@ -97,7 +97,7 @@ struct stac_model {
     int n_mlev_root = 0;        // micro-levels of the root-pass program currently in the blob (0 = none)
     int n_run_root = 0;         // of which the leading ones have work (n_mlev_root is padded to an even count)
     PlanHeader h3{};            // h with the chain layout of a lean launch (split kinematics, PlanHeader::fk3); valid when h.fk3
-    int fk3r[3] = {0, 0, 0};  // the pruned FK3 program currently in the blob: n1, n2, n3 (n3 = 0: none)
+    int fk3r = 0;  // the pruned FK3 program currently in the blob: its counts packed like PlanHeader::fk3_n (0: none)
     std::vector<float> h_bpos;  // body_pos of the active bodies, by slot
     int32_t *d_lm_tab = nullptr;
     size_t lm_tab_words = 0;
@@ -837,16 +837,16 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                 ok = build_fk3_program(m, g, nullptr, g.fk3_cap1, g.fk3_cap2, g.fk3_cap3, full);
                 if (ok) {
                     g.fk3 = 1;
-                    g.fk3_n1 = full.n1; g.fk3_n2 = full.n2; g.fk3_n3 = full.n3;
+                    g.fk3_n = full.n1 | full.n3 << 8 | full.n2 << 16;
                     g.off3_prog = put_raw(full.words.data(), full.words.size());
                     g.off3_site = g.off3_prog + 16 * (g.fk3_cap1 + 2) + 4 * g.fk3_cap2 + 4 * g.fk3_cap3;
                     std::vector<int32_t> blank3(full.words.size(), 0);
                     g.off3_root = put_raw(blank3.data(), blank3.size());
                     // what both layouts share
-                    const int32_t keep[] = {g.fk3, g.off3_site, g.off3_prog, g.off3_root, g.fk3_n1, g.fk3_n2, g.fk3_n3,
+                    const int32_t keep[] = {g.fk3, g.off3_site, g.off3_prog, g.off3_root, g.fk3_n,
                                             g.fk3_cap1, g.fk3_cap2, g.fk3_cap3};
-                    h.fk3 = keep[0]; h.off3_site = keep[1]; h.off3_prog = keep[2]; h.off3_root = keep[3]; h.fk3_n1 = keep[4]; h.fk3_n2 = keep[5];
-                    h.fk3_n3 = keep[6]; h.fk3_cap1 = keep[7]; h.fk3_cap2 = keep[8]; h.fk3_cap3 = keep[9];
+                    h.fk3 = keep[0]; h.off3_site = keep[1]; h.off3_prog = keep[2]; h.off3_root = keep[3]; h.fk3_n = keep[4];
+                    h.fk3_cap1 = keep[5]; h.fk3_cap2 = keep[6]; h.fk3_cap3 = keep[7];
                     h.c3_ql = g.c3_ql; h.c3_qb = g.c3_qb; h.c3_pb = g.c3_pb; h.c3_rw0 = g.c3_rw0; h.stride3 = g.stride3;
                     m->h3 = g;
                 }
@@ -1209,7 +1209,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         PlanHeader hh = m->h3;
         hh.plan_skip = m->h.off_joint;
         const int area = 16 * (hh.fk3_cap1 + 2) + 4 * hh.fk3_cap2 + 4 * hh.fk3_cap3 + hh.K + hh.naj;
-        hh.total_words = (q.do_root_opt && q.fk3r_n3 > 0) ? hh.off3_root + area : hh.off3_root;
+        hh.total_words = (q.do_root_opt && q.fk3r_n != 0) ? hh.off3_root + area : hh.off3_root;
         return hh;
     };
     const bool likely_lean = m->h.fk3 && !a.single && !a.bounds && !dbg.nolean && !(dbg.flags >= 0 && dbg.flags != 0);
@@ -1660,7 +1660,7 @@ static int run_q_lm(stac_model *m, const stac_q_params *p, QArgs &a, int nchains
 static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enable, int n_root_joints, hipStream_t s) {
     const PlanHeader &h = m->h;
     m->n_mlev_root = 0;
-    for (int &v : m->fk3r) v = 0;
+    m->fk3r = 0;
     if (!enable || m->dbg.noprune) return STAC_OK;
     std::vector<char> need(h.nab, 0);
     int n_need = 0;
@@ -1685,7 +1685,7 @@ static int fill_root_program(stac_model *m, const uint8_t *trunk_kps, bool enabl
             int32_t *d3 = reinterpret_cast<int32_t *>(m->blob_host.data()) + h.off3_root;
             std::memcpy(d3, rp.words.data(), rp.words.size() * 4);
             HIP_TRY(hipMemcpyAsync(m->d_blob + h.off3_root, d3, rp.words.size() * 4, hipMemcpyHostToDevice, s));
-            m->fk3r[0] = rp.n1; m->fk3r[1] = rp.n2; m->fk3r[2] = rp.n3;
+            m->fk3r = rp.n1 | rp.n3 << 8 | rp.n2 << 16;
         }
     }
     return STAC_OK;
@@ -1789,7 +1789,7 @@ extern "C" int32_t stac_q_phase(const stac_model *mc, const stac_q_params *p, co
     a.n_mlev_root = do_root_opt ? m->n_mlev_root : 0;
     a.n_run_root = do_root_opt ? m->n_run_root : 0;
     a.n_root_joints = n_root_joints;
-    if (do_root_opt && m->h.fk3) { a.fk3r_n1 = m->fk3r[0]; a.fk3r_n2 = m->fk3r[1]; a.fk3r_n3 = m->fk3r[2]; }
+    if (do_root_opt && m->h.fk3) a.fk3r_n = m->fk3r;
     // Root fast trips (QArgs::root_fast): the root coordinates are the first root_dims (<= 8: register 0 of every lane
     // group of 8 or more lanes) and belong to leading joints that share ONE subtree range, whose weighted sites fit a 64-bit mask
     if (do_root_opt && m->n_mlev_root > 0 && n_root_joints >= 1 && n_root_joints < m->h.naj && root_dims <= 8 && K <= 64 && !m->dbg.nofast) {

@@ -154,7 +154,7 @@ enum PinClass { PIN_N = 0, PIN_S = 1, PIN_V = 2, PIN_C = 3 };
     X(c_ja, STAC_PIN_ADDR) X(c_jn, STAC_PIN_ADDR) X(c_sw, STAC_PIN_ADDR) X(c_sink, STAC_PIN_ADDR) X(c_rw, STAC_PIN_ADDR)        \
     X(c_qe, STAC_PIN_ADDR) X(c_qsv, STAC_PIN_ADDR) X(chain_stride, STAC_PIN_ADDR)                                              \
     X(c3_ql, STAC_PIN_ADDR) X(c3_qb, STAC_PIN_ADDR) X(c3_pb, STAC_PIN_ADDR) X(c3_rw0, STAC_PIN_ADDR) X(off3_prog, STAC_PIN_ADDR) \
-    X(off3_root, STAC_PIN_ADDR) X(off3_site, STAC_PIN_ADDR) X(fk3_n1, STAC_PIN_CTL2) X(fk3_n2, STAC_PIN_CTL2) X(fk3_n3, STAC_PIN_CTL2) \
+    X(off3_root, STAC_PIN_ADDR) X(off3_site, STAC_PIN_ADDR) X(fk3_n, STAC_PIN_CTL2) \
     X(fk3_cap1, STAC_PIN_CTL2) X(fk3_cap2, STAC_PIN_CTL2) X(fk3_cap3, STAC_PIN_CTL2)
 #define STAC_HOT_ARGS_FIELDS(X)                                                                                                \
     X(single, STAC_PIN_CTL) X(P, STAC_PIN_CTL2) X(flags, STAC_PIN_CTL) X(free0p, STAC_PIN_CTL) X(root_fast, STAC_PIN_CTL)       \
@@ -172,7 +172,7 @@ constexpr bool is_pinned() { return C == PIN_S || (C == PIN_V && (VPIN & 1)) || 
 struct HotHeader {  // PlanHeader fields of every trip (values)
     int32_t nq, K, nqpad, naj, nrange, max_width, off_joint, off_site, off_lb, off_ub, off_range, off_fkstep, off_fkroot, fk_hdr_words,
         n_mlev_hdr, n_mlev, fk_rec_words, fk_uniform, c_bx, c_ja, c_jn, c_sw, c_sink, c_rw, c_qe, c_qsv, chain_stride;
-    int32_t c3_ql, c3_qb, c3_pb, c3_rw0, off3_prog, off3_root, off3_site, fk3_n1, fk3_n2, fk3_n3, fk3_cap1, fk3_cap2, fk3_cap3;  // split kinematics
+    int32_t c3_ql, c3_qb, c3_pb, c3_rw0, off3_prog, off3_root, off3_site, fk3_n, fk3_cap1, fk3_cap2, fk3_cap3;  // split kinematics
 };
 template <int VPIN, class KH>
 __device__ __forceinline__ HotHeader pin_header(const KH &h) {  // before the loop: the pinned ones
@@ -198,7 +198,7 @@ __device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH
                       k.stride_forced, k.nst, k.nqj, k.kpow2,
                       k.fk3, k.stride3};
 }
-static_assert(sizeof(PlanHeader) == (27 + 15 + 21 + 2) * 4, "TripHeader must list every PlanHeader field");
+static_assert(sizeof(PlanHeader) == (27 + 15 + 19 + 2) * 4, "TripHeader must list every PlanHeader field");
 struct HotArgs {  // QArgs fields of every trip (values)
     int32_t single, P, flags, free0p, root_fast, n_mlev_root, n_run_root, n_root_joints, maxls, maxiter, queue_slots, resume;
     uint32_t root_trunk_lo, root_trunk_hi;
@@ -213,7 +213,7 @@ __device__ __forceinline__ HotArgs pin_args(const KA &a) {
     return o;
 }
 struct TripArgs : HotArgs {
-    KRef<int32_t> fk3r_n1, fk3r_n2, fk3r_n3;
+    KRef<int32_t> fk3r_n;
     KRef<const float *> kp, q_init;
     KRef<const uint8_t *> kpw, kpw3;
     KRef<const int32_t *> perm;
@@ -229,7 +229,7 @@ __device__ __forceinline__ TripArgs trip_args(const HotArgs &hot, const KA &k) {
 #define STAC_PIN(f, c) if constexpr (!is_pinned<VPIN, STAC_PINCLASS(c)>()) t.f = k.f;
     STAC_HOT_ARGS_FIELDS(STAC_PIN)
 #undef STAC_PIN
-    return TripArgs{t, k.fk3r_n1, k.fk3r_n2, k.fk3r_n3, k.kp, k.q_init, k.kpw, k.kpw3, k.perm, k.C, k.F, k.root_kp_idx, k.do_root_opt, k.ctl, k.hand, k.qpos_out, k.err_out,
+    return TripArgs{t, k.fk3r_n, k.kp, k.q_init, k.kpw, k.kpw3, k.perm, k.C, k.F, k.root_kp_idx, k.do_root_opt, k.ctl, k.hand, k.qpos_out, k.err_out,
                     k.counters_out, k.q_carry_out};
 }
 

@@ -486,7 +486,7 @@ void q_phase_kernel(const QArgs a_in) {
         // root passes weigh the trunk keypoints only: when every live chain of the wave is in one, the kinematics stop at
         // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)
         const bool root_pass = !a.single && kind < 2;
-        const int n_mlev_root_a = LEAN ? a.fk3r_n3 : a.n_mlev_root;  // (lean: the pruned split-kinematics program, if the call has one)
+        const int n_mlev_root_a = LEAN ? a.fk3r_n : a.n_mlev_root;  // (lean: the pruned split-kinematics program, if the call has one)
         const int n_ml_root = (n_mlev_root_a > 0 && !__any(live_in && !root_pass)) ? n_mlev_root_a : 0;
         // root fast trip: only the root coordinates are staged and only the root joint's local transform is refreshed
         // (lite) once the other joints' local quaternions sit untouched in their ja entries
@@ -635,9 +635,10 @@ void q_phase_kernel(const QArgs a_in) {
             G3.T2 = pg + 16 * (H.fk3_cap1 + 2);
             G3.T3 = reinterpret_cast<const int *>(G3.T2 + 4 * H.fk3_cap2);
             G3.site = G3.T3 + 4 * H.fk3_cap3;
-            G3.n1 = rootp ? a.fk3r_n1 : H.fk3_n1;
-            G3.n2 = rootp ? a.fk3r_n2 : H.fk3_n2;
-            G3.n3 = rootp ? a.fk3r_n3 : H.fk3_n3;
+            const int n123 = rootp ? n_ml_root : H.fk3_n;  // (one word for the three counts: one select, no branch round three loads)
+            G3.n1 = n123 & 0xFF;
+            G3.n3 = (n123 >> 8) & 0xFF;
+            G3.n2 = (int)((unsigned)n123 >> 16);
             site3 = G3.site;
 #if defined(STAC_PROFILE) && defined(STAC_PROF_FK3)  // (diagnostic: the three passes charged to stamps 2, 4 and 9)
             {

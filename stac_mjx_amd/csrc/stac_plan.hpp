@@ -184,7 +184,7 @@ struct PlanHeader {
                            // build_fk3_program, stac_abi.hip), T2 [cap2][4] {v.x, v.y, v.z, q word | out word << 16}, T3 [cap3 * 4]: per block of
                            // four steps and position the restart entry (word of the value, or bit 31 | a valid word), then the site and joint words
     int32_t off3_root;     // same layout: the pruned program of the root passes (filled per call)
-    int32_t fk3_n1, fk3_n2, fk3_n3;   // steps of P1 (even), tasks of P2 (padded to a multiple of 32 with no-ops), steps of P3 (a multiple of 4): full program
+    int32_t fk3_n;         // full program: steps of P1 (even) | steps of P3 (a multiple of 4) << 8 | tasks of P2 (padded to a multiple of 32 with no-ops) << 16
     int32_t fk3_cap1, fk3_cap2, fk3_cap3;  // capacity of either program area (steps / tasks): where T2, T3 and the site words start
     int32_t c3_ql;         // [naj * 4] joint-local quaternions (w, x, y, z) by active joint; the range sums of a full trip alias it
     int32_t c3_qb;         // [naj * 4] quaternion AFTER every active joint (w, x, y, z); entry 0 = the free root's
@@ -234,7 +234,7 @@ struct QArgs {
     int32_t n_mlev_root;    // micro-levels of the root-pass FK program at h.off_fkroot; 0 = none (never prune)
     int32_t n_run_root;     // steps of that program that have work (<= n_mlev_root, which is padded to an even count)
     int32_t n_root_joints;  // leading active joints that carry the root passes' coordinates
-    int32_t fk3r_n1, fk3r_n2, fk3r_n3;  // the pruned FK3 program at h.off3_root (PlanHeader::fk3_*): steps of P1, tasks of P2, steps of P3
+    int32_t fk3r_n;  // the pruned FK3 program at h.off3_root, packed like PlanHeader::fk3_n (0: none)
     // Root fast trips (throughput kernels).  While every live chain of a wavefront is in a root solve, only the first
     // root_fast coordinates move: the joint-local quaternions of all other joints, computed once, stay valid (the root
     // program parks their anchor / pre-joint entries in the sink), the gradient is the root joint's alone and its subtree
