@@ -931,8 +931,8 @@ constexpr long kSpec4MinChains = 1L << 40;
 // 160 KiB of a CU.  Returns the wpb (1..8) that maximises resident chains per CU for this G.
 // Launch shape for a given G: wavefronts per workgroup (the waves of a block share one plan copy) and the
 // register-cap variant.  wpe = 2 keeps everything in registers (<= 256 VGPRs, 8 waves per CU); wpe = 3
-// (<= 168 VGPRs, 16-lane groups only) holds ten waves as ONE workgroup (3,3,2,2 over the SIMDs; two 5-wave
-// workgroups could stack four waves on a SIMD); wpe = 4 (<= 128 VGPRs, more spills to scratch) admits 16 waves
+// (<= 168 VGPRs, 16-lane groups only) holds up to twelve waves as ONE workgroup (eleven: 3,3,3,2 over the SIMDs; two 5-wave
+// workgroups could stack four waves on a SIMD -- the lean rodent layout fits eleven: 100 000 frames 649 -> 720 k frames/s); wpe = 4 (<= 128 VGPRs, more spills to scratch) admits 16 waves
 // per CU.  LDS is allocated in granules (1280 B observed on gfx950: five 32 224-B workgroups do not
 // fit a CU).
 struct QShape { int wpb, wpe, waves_per_cu; };
@@ -941,7 +941,7 @@ static QShape pick_shape(const PlanHeader &h, int G, int nkinds, long waves_need
     QShape best{0, 2, 0};
     for (int wpe = 2; wpe <= 4; ++wpe) {
         if (!(lean ? q_phase_has_lean_variant(G, h.nq, wpe, 0) : q_phase_has_variant(G, h.nq, wpe))) continue;  // (stac_kernels.hip, STAC_Q_SHAPES: only shapes that pass the spill gate are built)
-        for (int wpb = 1; wpb <= (wpe == 3 ? 10 : 8); ++wpb) {
+        for (int wpb = 1; wpb <= (wpe == 3 ? 12 : 8); ++wpb) {
             size_t lds = q_lds_bytes(h, G, nkinds, wpb);
             if (lds > kLdsPerCu) break;
             lds = (lds + kGranule - 1) / kGranule * kGranule;
@@ -1324,7 +1324,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         }
         if (dbg.wpb >= 0) {  // developer overrides
             const int ww = dbg.wpb;
-            if (ww >= 1 && ww <= (sh.wpe == 3 ? 10 : 8) && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
+            if (ww >= 1 && ww <= (sh.wpe == 3 ? 12 : 8) && q_lds_bytes(a.h, G, nkinds, ww) <= kLdsPerCu) sh.wpb = ww;
         }
         if (dbg.verbose)
             fprintf(stderr, "[stac] q_phase: chains=%d G=%d%s wpb=%d wpe=%d waves/CU=%d lds=%zu B/block chain_stride=%d floats plan=%d words\n",

@@ -60,7 +60,7 @@ namespace stac {
 // registers; no developer flags) as compile-time constants inside the trip loop: the other paths drop out of the loop body
 // (10 % fewer instructions, no scalar spills).  The host takes it when all of that holds (launch_q_phase); same bits.
 template <int G, int NQR, int WPE, int SPECP>
-__global__ __launch_bounds__(WPE == 3 ? 640 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+__global__ __launch_bounds__(WPE == 3 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void q_phase_kernel(const QArgs a_in) {
     constexpr int SPEC = SPECP & ~1;
     constexpr bool LEAN = (SPECP & 1) != 0;
