@@ -482,7 +482,7 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
     int n3 = fk3_schedule(o3, 4, 5);
     if (n3 > 0) n3 = (n3 + 3) & ~3;  // P3 runs whole blocks of four steps
     const int n2 = ((int)o3.size() + 31) & ~31;
-    if (n1 < 0 || n3 < 0 || n1 > 64 || n3 > 64 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;
+    if (n1 < 0 || n3 < 0 || n1 > 254 || n3 > 252 || n1 > cap1 || n3 > cap3 || n2 > cap2) return false;  // (eight bits each in PlanHeader::fk3_n)
     const int root_slot = cap3 * 4, sink_slot = cap3 * 4 + 1;
     auto pbw = [&](int op) { return h3.c3_pb + 3 * (op < 0 ? root_slot : o3[op].t * 4 + o3[op].pp); };
     auto qbw = [&](int node) { return h3.c3_qb + 4 * node; };
@@ -803,7 +803,10 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     {   // Split kinematics (PlanHeader::fk3; stac_plan.hpp): a free root at qpos 0 .. 6 on the ONE top-level active body, hinges
         // below it, no oriented body.  The lean kernels run nothing else, so a model without it takes the generic kernels.
         h.fk3 = 0;
-        bool ok = naj >= 1 && aj_type[0] == STAC_JNT_FREE && aj_qadr[0] == 0 && !any_bquat && nqj == 1 && !has_ball &&
+        // (the free root's own body may be oriented: a free joint sets the body's pose, body_pos / body_quat do not enter -- mouse)
+        bool bquat_below = false;
+        for (int s2 = 1; s2 < nab; ++s2) bquat_below = bquat_below || !(brec[s2].flags & 1);
+        bool ok = naj >= 1 && aj_type[0] == STAC_JNT_FREE && aj_qadr[0] == 0 && ab_jnum[0] >= 1 && ab_jadr[0] == 0 && !bquat_below && nqj == 1 && !has_ball &&
                   getenv("STAC_HIP_NOFK3") == nullptr;
         for (int j = 1; j < naj && ok; ++j) ok = aj_type[j] == STAC_JNT_HINGE;
         for (int s = 1; s < nab && ok; ++s) ok = ab_parent[s] != 0;
@@ -812,7 +815,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
             // capacities of a program area: the full program's own sizes (a pruned program is a sub-DAG: it is checked against them)
             Fk3Program probe;
             g.c3_qb = 0; g.c3_pb = 0; g.c3_ql = 0; g.stride3 = 1;
-            ok = build_fk3_program(m, g, nullptr, 64, 4096, 64, probe);
+            ok = build_fk3_program(m, g, nullptr, 254, 4096, 252, probe);
             if (ok) {
                 // (cap1 even, >= 10: the table area 16 (cap1 + 2) holds cap1 / 2 + 3 records of 24 words; cap3: whole blocks)
                 g.fk3_cap1 = std::max(probe.n1, 10); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 4);
@@ -1134,29 +1137,35 @@ extern "C" int32_t stac_fk(const stac_model *m, const float *qpos, int32_t N, fl
 // i.e. the latency mode up to about 2.3 x its resident capacity, then 32 lanes until the 16-lane kernel has
 // about 45 % of its slots filled (8 and 4 lanes only on request: with the LDS footprint of a chain they cannot
 // keep two waves per SIMD resident).  Returns 0 for the latency mode.
-static int pick_lanes(const stac_model *m, const PlanHeader &mh, int requested, int nchains, int nkinds, bool spec_allowed, int frames) {
-    // (mh: the model's header with the chain layout this call's launches will most likely have -- lean or generic)
+static int pick_lanes(const stac_model *m, const PlanHeader *lean_h, int requested, int nchains, int nkinds, bool spec_allowed, int frames) {
+    // (lean_h: the header a lean launch of this call would stage -- chain layout of the split kinematics, plan from the joint records
+    //  on --, or null when the call cannot be lean.  Every candidate width is sized with the header ITS launch would get: the lean one
+    //  where a lean instantiation holds nq at that width, the generic one elsewhere (mouse: lean at 32 lanes only))
+    const int nq = m->h.nq;
+    auto thr_lean = [&](int G) { return lean_h && (q_phase_has_lean_variant(G, nq, 2, 0) || q_phase_has_lean_variant(G, nq, 3, 0)); };
+    auto thr_shape = [&](int G) { const bool ln = thr_lean(G); return pick_shape(ln ? *lean_h : m->h, G, nkinds, -1, ln); };
+    auto spec_hdr = [&](int G, int nr) -> const PlanHeader & { return lean_h && q_phase_has_lean_variant(G, nq, 2, nr) ? *lean_h : m->h; };
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
-        const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(mh, kLatG, nkinds, -1, kLatR)  // one chain per wave
-                                                  : pick_spec_shape(mh, 32, nkinds);
+        const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(spec_hdr(kLatG, kLatR), kLatG, nkinds, -1, kLatR)  // one chain per wave
+                                                  : pick_spec_shape(spec_hdr(32, 8), 32, nkinds);
         // Measured crossover against the throughput kernel (rodent, profiles/r03/shape_sweep.txt): 1.8 x the resident chains
         // for single-frame clips, 2.3 x for two or three frames, 2.6 x from four frames on (the longer a clip, the less
         // of it are the root solves that the throughput kernel runs as fast trips)
         const long x10 = frames <= 1 ? 18 : (frames < 4 ? 23 : 26);
         if (ss.resident && (long)nchains * 10 <= ss.resident * x10) return 0;
     }
-    const QShape s16 = pick_shape(mh, 16, nkinds);
+    const QShape s16 = thr_shape(16);
     {   // Models whose chains are so large that 16-lane groups leave a wavefront or less per SIMD (mouse: 6.9 KB of LDS per chain,
         // three 4-chain wavefronts per CU): 32-lane groups hold MORE chains per CU there (seven 2-chain wavefronts) and halve
         // the rounds of every per-coordinate and per-joint phase -- 27.3 k -> 36.4 k frames/s on 10 000 mouse frames.
-        const QShape s32 = pick_shape(mh, 32, nkinds);
+        const QShape s32 = thr_shape(32);
         if (s16.wpb && s32.wpb && s32.waves_per_cu * 2 > s16.waves_per_cu * 4 && m->h.max_width * 4 <= 32 &&
             (long)nchains * 100 > (long)s32.waves_per_cu * kCus * 2 * 45)
             return 32;
     }
     if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 25) return 16;  // (from a quarter of the resident slots on: 16 lanes beat 32 at every measured size above the latency kernel's range)
-    if (nchains > 2500 && pick_shape(mh, 32, nkinds).wpb) return 32;
+    if (nchains > 2500 && thr_shape(32).wpb) return 32;
     return 64;
 }
 
@@ -1213,10 +1222,10 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         return hh;
     };
     const bool likely_lean = m->h.fk3 && !a.single && !a.bounds && !dbg.nolean && !(dbg.flags >= 0 && dbg.flags != 0);
-    const PlanHeader &mh = likely_lean ? m->h3 : m->h;
+    const PlanHeader lean_h = likely_lean ? lean_header(a) : m->h;
     // (clip length for the latency / throughput crossover; without root optimisation -- the tethered fly -- a single-frame clip
     //  has no root solves for the throughput kernel to run as fast trips: counted like a two-frame clip, measured)
-    int G = pick_lanes(m, mh, p->lanes_per_chain, nchains, nkinds, !a.single, a.single ? 1 : (a.do_root_opt ? a.F : std::max(a.F, 2)));
+    int G = pick_lanes(m, likely_lean ? &lean_h : nullptr, p->lanes_per_chain, nchains, nkinds, !a.single, a.single ? 1 : (a.do_root_opt ? a.F : std::max(a.F, 2)));
     hipError_t e = hipErrorInvalidValue;
     int cap = 0;
     // Latency mode: when there are so few chains that each would get a whole wavefront anyway (G = 64), let
@@ -1230,7 +1239,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // (measured, rodent, 250-frame clips: DESIGN.md 2.1), else one wavefront per chain
         int sg = kLatG;
         {
-            const SpecShape s64 = pick_spec_shape(mh, 64, nkinds), s32 = pick_spec_shape(mh, 32, nkinds);
+            const bool l32 = likely_lean && q_phase_has_lean_variant(32, m->h.nq, 2, 8);
+            const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(l32 ? lean_h : m->h, 32, nkinds);
             if (s64.resident && (long)nchains <= kSpec64MaxChains) sg = 64;
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
         }

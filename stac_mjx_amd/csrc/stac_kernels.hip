@@ -132,7 +132,7 @@ void q_phase_kernel(const QArgs a_in) {
     float *qe = sw, *kpl = CB + H.c_kp;
     // Sites k = r * G + lg, r < kSiteRounds, belong to this lane: their keypoints and loss terms stay in registers when
     // that covers all K sites (the host then lays the chain out without the c_kp / c_r2 regions); else through LDS.
-    constexpr int NSR = LEAN ? lean_site_rounds(G) : kSiteRounds;
+    constexpr int NSR = LEAN ? lean_site_rounds(G, NQR) : kSiteRounds;
     const bool site_regs = K <= NSR * G;
     float kpr[NSR][3];
 #pragma unroll
@@ -1718,7 +1718,7 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 #define STAC_Q_SPEC_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #else
 // lean kernels (SPECP bit 0): the shapes that rodent-sized models run in -- large batches, the straggler hand-off, few long clips
-#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2)
+#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2) X(32, 8, 2)
 #define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(16, 5, 8) X(32, 3, 8)
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
@@ -1757,8 +1757,13 @@ bool q_phase_has_lean_variant(int G, int nq, int wpe, int spec) {
 // (PlanHeader::fk3: stac_plan.hpp), every site in registers at this group width.  The host decides with it which chain layout
 // the launch gets (run_q) and passes its decision to launch_q_phase.
 bool q_phase_lean_conditions(const QArgs &a, int G) {
-    return !a.single && !a.bounds && a.flags == 16 && a.free0p == 1 && a.h.fk3 == 1 && a.h.K <= lean_site_rounds(G) * G && a.h.nqj == 1 &&
-           !a.h.has_ball && G >= 16;
+    int nqr = 0;  // solver registers per lane of the lean instantiation that holds nq at this width (the same for every register cap / role count)
+#define STAC_NQR(GG, RR, WW) if (G == GG && a.h.nq <= GG * RR && (nqr == 0 || RR < nqr)) nqr = RR;
+    STAC_Q_LEAN_SHAPES(STAC_NQR)
+    STAC_Q_SPEC_LEAN_SHAPES(STAC_NQR)
+#undef STAC_NQR
+    return !a.single && !a.bounds && a.flags == 16 && a.free0p == 1 && a.h.fk3 == 1 && nqr > 0 && a.h.K <= lean_site_rounds(G, nqr) * G &&
+           a.h.nqj == 1 && !a.h.has_ball && G >= 16;
 }
 
 // wpb = wavefronts per workgroup (they share the plan copy), wpe = register-cap variant (2, 3 or 4 wavefronts per SIMD; the

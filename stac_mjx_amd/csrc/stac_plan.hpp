@@ -17,7 +17,8 @@ constexpr int kSiteRounds = 3;
 // The lean kernels (stac_kernels.hip) take the sites in as many rounds as a rodent-sized marker set needs at their group width
 // (K <= 32: two rounds of 16 lanes, one of 32) instead of three of which the last ones are empty: the host checks K against it
 // (launch_q_phase).  The loss tree is the same sum: the registers that fall away held +0, and a sum of squares is never -0.
-constexpr int lean_site_rounds(int G) { return G >= 32 ? 1 : (G >= 16 ? 2 : kSiteRounds); }
+// (NQR: solver registers per lane of the instantiation -- the wide models' shapes, more than four, take two rounds at 32 lanes)
+constexpr int lean_site_rounds(int G, int NQR) { return G >= 32 ? (NQR > 4 ? 2 : 1) : (G >= 16 ? 2 : kSiteRounds); }
 // A transform entry in a chain's LDS region: position (3 words) then quaternion (4 words, in the order x, y, z, w).  Used for the body
 // transforms (c_bx), the per-joint {anchor, pre-joint quaternion} entries (c_ja; the pre-pass parks the joint-local
 // quaternion in the quaternion words) and, as {f, t}, for the site wrenches and range sums.  Packed (7 words) by
