@@ -1152,7 +1152,9 @@ static int pick_lanes(const stac_model *m, const PlanHeader *lean_h, int request
         // Measured crossover against the throughput kernel (rodent, profiles/r03/shape_sweep.txt): 1.8 x the resident chains
         // for single-frame clips, 2.3 x for two or three frames, 2.6 x from four frames on (the longer a clip, the less
         // of it are the root solves that the throughput kernel runs as fast trips)
-        const long x10 = frames <= 1 ? 18 : (frames < 4 ? 23 : 26);
+        // (four wavefronts per chain -- models too wide for one wavefront per chain: mouse --: 3.2 x from four frames on, measured
+        //  with the lean kernels: 700 chains 51.6 k against 45.7 k frames/s, 1 000 chains 54.8 k against 65.2 k)
+        const long x10 = frames <= 1 ? 18 : (frames < 4 ? 23 : (lat_one_wave_ok(m->h) ? 26 : 32));
         if (ss.resident && (long)nchains * 10 <= ss.resident * x10) return 0;
     }
     const QShape s16 = thr_shape(16);
@@ -1164,6 +1166,9 @@ static int pick_lanes(const stac_model *m, const PlanHeader *lean_h, int request
             (long)nchains * 100 > (long)s32.waves_per_cu * kCus * 2 * 45)
             return 32;
     }
+    // (a model whose only lean width is 32 -- more coordinates than the 16-lane lean shapes hold: mouse -- stays on it: the generic
+    //  kernels run the step-program kinematics, 2.2 x slower on its 84-product spine)
+    if (thr_lean(32) && !thr_lean(16) && thr_shape(32).wpb) return 32;
     if (s16.wpb && (long)nchains * 100 > (long)s16.waves_per_cu * kCus * 4 * 25) return 16;  // (from a quarter of the resident slots on: 16 lanes beat 32 at every measured size above the latency kernel's range)
     if (nchains > 2500 && thr_shape(32).wpb) return 32;
     return 64;

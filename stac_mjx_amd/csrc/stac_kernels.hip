@@ -1719,7 +1719,7 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 #else
 // lean kernels (SPECP bit 0): the shapes that rodent-sized models run in -- large batches, the straggler hand-off, few long clips
 #define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2) X(32, 8, 2)
-#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(16, 5, 8) X(32, 3, 8)
+#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(16, 5, 8) X(32, 3, 8) X(32, 8, 8)
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
     X(16, 5, 2) X(16, 5, 3) X(16, 8, 2) X(16, 8, 3) X(16, 16, 2)                 \

@@ -1183,9 +1183,11 @@ _SHAPE_CASES = [
     ("mid", 32, "pg", {"STAC_HIP_WPE": "2"}),                                   # q<32,4,2,0>
     ("mid", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),           # q<16,8,2,4>
     ("mouse", 16, "pg", {}),                                                    # q<16,16,2,0>
-    ("mouse", 32, "pg", {}),                                                    # q<32,8,2,0>
+    ("mouse", 32, "pg", {}),                                                    # q<32,8,2,1>  (lean: the wide shape, two rounds of sites)
+    ("mouse", 32, "pg", {"STAC_HIP_NOLEAN": "1"}),                              # q<32,8,2,0>  (generic)
     ("mouse", 64, "pg", {"STAC_HIP_WPE": "2"}),                                 # q<64,4,2,0>
-    ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),         # q<32,8,2,8>
+    ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),         # q<32,8,2,9>  (lean)
+    ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32", "STAC_HIP_NOLEAN": "1"}),   # q<32,8,2,8>  (generic)
     ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "64"}),         # q<64,4,2,8>
     ("rodent", 16, "lm", {}), ("rodent", 32, "lm", {}), ("rodent", 64, "lm", {}),     # lm<16,5,2> lm<32,3,2> lm<64,2,3>
     ("mid", 16, "lm", {}),                                                      # lm<16,8,2>
