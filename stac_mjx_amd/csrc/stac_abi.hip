@@ -1360,7 +1360,8 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         if (!a.single && !(a.flags & 3) && (lean_b || m->h.max_width <= kLatG) && lat_one_wave_ok(m->h)) {
             const int spec_cap = (int)pick_spec_shape(hb, kLatG, nkinds, -1, kLatR).resident;
             // worth it while the tail is a sizeable part of the launch: up to about three rounds of resident chains
-            if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains / 5);
+            // (15 % of the chains: 1 500 of 10 000 run like 2 000 -- 564-575 k against 567-572 k frames/s -- and move 1 MB less through HBM)
+            if (nchains >= 4096 && (long)nchains <= 3L * sh.waves_per_cu * kCus * (64 / G)) hcap = std::min(spec_cap, nchains * 3 / 20);
             if (dbg.handoff >= 0) hcap = spec_cap ? std::min(dbg.handoff, nchains) : 0;
         }
         // Chain queue: when the launch has more chains than resident slots, the grid covers the resident slots only and
