@@ -1256,6 +1256,32 @@ def test_split_kinematics_and_step_program_agree_bit_for_bit(rodent_setup, roden
             assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (name, key)
 
 
+def test_default_launches_of_the_mouse_take_the_wide_lean_kernels(mouse_setup):
+    """Round 5: a model too wide for the 16-lane lean shapes (mouse: 230 coordinates, an oriented free-root body) runs the split
+    kinematics in the 32-lane shapes with eight solver registers per lane, at every batch size, by the host's own choice -- and equals
+    the oracle there (the generic kernels spent 79 % of a trip in the step program of its 84-product spine)."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    fs = mouse_setup
+    t = fs.tables
+    orc = Oracle(t, tol=1e-4, maxiter=10)
+    rng = np.random.default_rng(5)
+    qm = t.qpos0[None] + np.clip(rng.normal(0, 0.05, (4, t.nq)), -0.1, 0.1).astype(np.float32)
+    qm[:, 3:7] = t.qpos0[3:7]
+    kp4 = np.stack([orc.fk(x)["site_xpos"].reshape(-1) for x in qm]).astype(np.float32)
+    kw = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=fs.do_root_opt)
+    eng = Engine(t, fs.lb, fs.ub, tol=1e-4, maxiter=10)
+    big = eng.q_phase(np.tile(kp4, (750, 1)).reshape(3000, 1, -1), **kw)      # throughput launch
+    assert _last_q_kernel(eng)[0] == 32 and _last_q_kernel(eng)[1] == 8 and _last_q_kernel(eng)[3] & 1
+    few = eng.q_phase(kp4.reshape(2, 2, -1), **kw)                              # latency launch
+    assert _last_q_kernel(eng) == (32, 8, 2, 9)
+    ref1 = orc.ik_clips(kp4.reshape(4, 1, -1), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, do_root_opt=fs.do_root_opt)
+    np.testing.assert_array_equal(_np(big["qpos"])[:4].view(np.uint32), ref1["qpos"].view(np.uint32))
+    np.testing.assert_array_equal(_np(big["qpos"])[2996:].view(np.uint32), ref1["qpos"].view(np.uint32))
+    _compare_phase(few, orc.ik_clips(kp4.reshape(2, 2, -1), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, do_root_opt=fs.do_root_opt))
+
+
 @pytest.mark.parametrize("model,lanes,solver,env", _SHAPE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else
                          "-".join(f"{k[9:]}{x}" for k, x in v.items()) or "auto")
 def test_every_shipped_instantiation_twice(rodent_setup, mouse_setup, rodent_mocap, monkeypatch, model, lanes, solver, env):
