@@ -744,6 +744,17 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     h.off_joint = put_raw(jrec.data(), jrec.size() * sizeof(JointRec) / 4);
     h.off_site = put_raw(srec.data(), srec.size() * sizeof(SiteRec) / 4);
     h.off_range = put_raw(ranges.data(), ranges.size() * sizeof(RangeRec) / 4);
+    {   // momentum table (stac_plan.hpp, kTTab): the kernel's expressions, float32, no contraction (build flags)
+        std::vector<float> tt(2 * kTTab);
+        float tk = 1.0f;
+        for (int k = 0; k < kTTab; ++k) {
+            const float tn = 0.5f * (1.0f + std::sqrt(1.0f + 4.0f * tk * tk));
+            tt[2 * k] = tn;
+            tt[2 * k + 1] = (tk - 1.0f) / tn;
+            tk = tn;
+        }
+        (void)put_raw(tt.data(), tt.size());
+    }
     h.off_lb = put_fpad(t->lb, nq, h.nqpad);
     h.off_ub = put_fpad(t->ub, nq, h.nqpad);
     h.off_qpos0 = put_fpad(t->qpos0, nq, h.nqpad);

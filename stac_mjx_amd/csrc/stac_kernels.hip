@@ -480,8 +480,24 @@ void q_phase_kernel(const QArgs a_in) {
         // t_next and the momentum coefficient of the running iteration (functions of t only; recomputed every
         // trip instead of being carried); SPEC: this group's candidate scale 2^-c
         const float spec_pow = SPEC ? ((role % NC) == 0 ? 1.0f : (role % NC) == 1 ? 0.5f : (role % NC) == 2 ? 0.25f : 0.125f) : 1.0f;
-        const float spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
-        const float spec_beta = (t - 1.0f) / spec_tn;
+        // (t == t_iter: the throughput kernels take both from the plan's table while iter < kTTab -- a square root and a division less per
+        //  trip: +1.5-2 % on the 10 000-frame bench --; the latency kernels, which would wait for the read at once (measured: -0.5 %),
+        //  and the 128-register variants, which have no register left for it, compute them, like everyone beyond the table)
+        float spec_tn, spec_beta;
+        if constexpr (SPEC == 0 && WPE != 4) {
+            const float2 e = *reinterpret_cast<const float2 *>(lbv - 2 * kTTab + 2 * min(iter, kTTab - 1));
+            spec_tn = e.x;
+            spec_beta = e.y;
+            if (__any(iter >= kTTab)) {
+                const float tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
+                const float be = (t - 1.0f) / tn;
+                spec_tn = iter >= kTTab ? tn : spec_tn;
+                spec_beta = iter >= kTTab ? be : spec_beta;
+            }
+        } else {
+            spec_tn = 0.5f * (1.0f + __builtin_sqrtf(1.0f + 4.0f * t * t));
+            spec_beta = (t - 1.0f) / spec_tn;
+        }
 
         // root passes weigh the trunk keypoints only: when every live chain of the wave is in one, the kinematics stop at
         // the ancestors of those keypoints (the other sites contribute exact zeros, written as such below)

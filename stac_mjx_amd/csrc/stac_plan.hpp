@@ -14,6 +14,10 @@ constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 // A lane of a G-lane group takes the sites k = r * G + lane, r < kSiteRounds: their keypoints and loss terms stay in
 // registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
 constexpr int kSiteRounds = 3;
+// FISTA's momentum sequence t_0 = 1, t_(k+1) = (1 + sqrt(1 + 4 t_k^2)) / 2 depends on the iteration number alone: the plan holds
+// {t_(k+1), (t_k - 1) / t_(k+1)} for k < kTTab right in front of the lower bounds (PlanHeader::off_lb - 2 kTTab), computed on the host
+// with the kernel's own float32 expressions; later iterations compute them (stac_kernels.hip)
+constexpr int kTTab = 256;
 // The lean kernels (stac_kernels.hip) take the sites in as many rounds as a rodent-sized marker set needs at their group width
 // (K <= 32: two rounds of 16 lanes, one of 32) instead of three of which the last ones are empty: the host checks K against it
 // (launch_q_phase).  The loss tree is the same sum: the registers that fall away held +0, and a sum of squares is never -0.

@@ -1256,6 +1256,27 @@ def test_split_kinematics_and_step_program_agree_bit_for_bit(rodent_setup, roden
             assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (name, key)
 
 
+def test_solves_longer_than_the_momentum_table(rodent_setup, rodent_mocap, monkeypatch):
+    """Round 5: the throughput kernels read FISTA's t_(k+1) and (t_k - 1) / t_(k+1) from a table in the plan for the first 256
+    iterations of a solve and compute them beyond it; solves that never reach the tolerance run through both (280 iterations each)."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    fs = rodent_setup
+    monkeypatch.setenv("STAC_HIP_SPEC", "0")
+    kp = rodent_mocap[500:506].reshape(3, 2, 69)
+    kw = dict(part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=True)
+    orc = Oracle(fs.tables, tol=1e-12, maxiter=280)
+    ref = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims)
+    assert ref["counters"][..., 0].max() >= 6 * 280  # every solve of a frame ran to the bound
+    for lanes, env in ((16, {}), (16, {"STAC_HIP_NOLEAN": "1"}), (32, {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(fs.tables, fs.lb, fs.ub, tol=1e-12, maxiter=280, lanes_per_chain=lanes)
+        _compare_phase(_q_phase_twice(eng, kp, **kw), ref)
+        eng.close()
+
+
 def test_default_launches_of_the_mouse_take_the_wide_lean_kernels(mouse_setup):
     """Round 5: a model too wide for the 16-lane lean shapes (mouse: 230 coordinates, an oriented free-root body) runs the split
     kinematics in the 32-lane shapes with eight solver registers per lane, at every batch size, by the host's own choice -- and equals
