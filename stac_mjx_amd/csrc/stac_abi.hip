@@ -741,9 +741,6 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     }
     h.off_lev_adr = put_raw(lev_adr.data(), lev_adr.size());
     h.off_body = put_raw(brec.data(), brec.size() * sizeof(BodyRec) / 4);
-    h.off_joint = put_raw(jrec.data(), jrec.size() * sizeof(JointRec) / 4);
-    h.off_site = put_raw(srec.data(), srec.size() * sizeof(SiteRec) / 4);
-    h.off_range = put_raw(ranges.data(), ranges.size() * sizeof(RangeRec) / 4);
     {   // momentum table (stac_plan.hpp, kTTab): the kernel's expressions, float32, no contraction (build flags)
         std::vector<float> tt(2 * kTTab);
         float tk = 1.0f;
@@ -755,6 +752,9 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         }
         (void)put_raw(tt.data(), tt.size());
     }
+    h.off_joint = put_raw(jrec.data(), jrec.size() * sizeof(JointRec) / 4);
+    h.off_site = put_raw(srec.data(), srec.size() * sizeof(SiteRec) / 4);
+    h.off_range = put_raw(ranges.data(), ranges.size() * sizeof(RangeRec) / 4);
     h.off_lb = put_fpad(t->lb, nq, h.nqpad);
     h.off_ub = put_fpad(t->ub, nq, h.nqpad);
     h.off_qpos0 = put_fpad(t->qpos0, nq, h.nqpad);
@@ -1155,7 +1155,9 @@ static int pick_lanes(const stac_model *m, const PlanHeader *lean_h, int request
     const int nq = m->h.nq;
     auto thr_lean = [&](int G) { return lean_h && (q_phase_has_lean_variant(G, nq, 2, 0) || q_phase_has_lean_variant(G, nq, 3, 0)); };
     auto thr_shape = [&](int G) { const bool ln = thr_lean(G); return pick_shape(ln ? *lean_h : m->h, G, nkinds, -1, ln); };
-    auto spec_hdr = [&](int G, int nr) -> const PlanHeader & { return lean_h && q_phase_has_lean_variant(G, nq, 2, nr) ? *lean_h : m->h; };
+    PlanHeader lean_spec = lean_h ? *lean_h : m->h;  // (a lean latency launch stages from the joint records on: no momentum table)
+    if (lean_h) lean_spec.plan_skip += 2 * kTTab;
+    auto spec_hdr = [&](int G, int nr) -> const PlanHeader & { return lean_h && q_phase_has_lean_variant(G, nq, 2, nr) ? lean_spec : m->h; };
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
         const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(spec_hdr(kLatG, kLatR), kLatG, nkinds, -1, kLatR)  // one chain per wave
@@ -1230,15 +1232,17 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         return q_phase_has_lean_variant(lanes, m->h.nq, 2, 0) || q_phase_has_lean_variant(lanes, m->h.nq, 3, 0);
     };
     // a lean launch stages the plan from the joint records up to the split-kinematics tables (the root program only when it is used)
-    auto lean_header = [&](const QArgs &q) {
+    // (thr: a throughput launch -- it stages the momentum table, which stands right in front of the joint records; the latency kernels
+    //  compute the pair and leave it out: 2 KB that decide whether 1 000 two-wavefront chains are resident)
+    auto lean_header = [&](const QArgs &q, bool thr) {
         PlanHeader hh = m->h3;
-        hh.plan_skip = m->h.off_joint;
+        hh.plan_skip = m->h.off_joint - (thr ? 2 * kTTab : 0);
         const int area = 16 * (hh.fk3_cap1 + 2) + 4 * hh.fk3_cap2 + 4 * hh.fk3_cap3 + hh.K + hh.naj;
         hh.total_words = (q.do_root_opt && q.fk3r_n != 0) ? hh.off3_root + area : hh.off3_root;
         return hh;
     };
     const bool likely_lean = m->h.fk3 && !a.single && !a.bounds && !dbg.nolean && !(dbg.flags >= 0 && dbg.flags != 0);
-    const PlanHeader lean_h = likely_lean ? lean_header(a) : m->h;
+    const PlanHeader lean_h = likely_lean ? lean_header(a, true) : m->h;
     // (clip length for the latency / throughput crossover; without root optimisation -- the tethered fly -- a single-frame clip
     //  has no root solves for the throughput kernel to run as fast trips: counted like a two-frame clip, measured)
     int G = pick_lanes(m, likely_lean ? &lean_h : nullptr, p->lanes_per_chain, nchains, nkinds, !a.single, a.single ? 1 : (a.do_root_opt ? a.F : std::max(a.F, 2)));
@@ -1256,7 +1260,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         int sg = kLatG;
         {
             const bool l32 = likely_lean && q_phase_has_lean_variant(32, m->h.nq, 2, 8);
-            const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(l32 ? lean_h : m->h, 32, nkinds);
+            const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(l32 ? lean_header(a, false) : m->h, 32, nkinds);
             if (s64.resident && (long)nchains <= kSpec64MaxChains) sg = 64;
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;
         }
@@ -1275,12 +1279,12 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // (lean kernel only) -- one trip per iteration like the four-wavefront kernel instead of 1.16 longer ones (measured, 1 000 chains
         // of 250 frames: profiles/r05/NOTES.md)
         if (sg == 16 && dbg.specg < 0 && lean_for(a, 16, 8, true)) {
-            const SpecShape s2 = pick_spec_shape(lean_header(a), 16, nkinds, -1, 8);
+            const SpecShape s2 = pick_spec_shape(lean_header(a, false), 16, nkinds, -1, 8);
             if (s2.resident && (long)nchains <= s2.resident) sr = 8;
         }
         if (sg == 16 && dbg.specr == 8 && lean_for(a, 16, 8, true)) sr = 8;
         const bool lean = lean_for(a, sg, sr, true);
-        const PlanHeader hh = lean ? lean_header(a) : m->h;
+        const PlanHeader hh = lean ? lean_header(a, false) : m->h;
         const SpecShape sh = pick_spec_shape(hh, sg, nkinds, nchains, sr);
         if (sh.chains_per_block) {
             const size_t lds = spec_lds_bytes(hh, sg, nkinds, sh.chains_per_block, sr);
@@ -1318,7 +1322,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         a.h.plan_skip = 0;
         QShape sh{0, 2, 0};
         if (lean) {
-            a.h = lean_header(a);
+            a.h = lean_header(a, true);
             sh = pick_shape(a.h, G, nkinds, waves_needed, true);
             if (!sh.wpb) { a.h = m->h; a.flags = flags_in; continue; }
         } else {
@@ -1330,7 +1334,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
             // LDS diet of a program launch: no level tables / body records (they come first in the blob), and of the root
             // program (last) only the steps this call's trunk keypoints need -- or nothing without root optimisation
             if (m->h.off_lev_adr == 0 && m->h.off_body < m->h.off_joint && !dbg.nodiet) {
-                hp.plan_skip = m->h.off_joint;
+                hp.plan_skip = m->h.off_joint - 2 * kTTab;  // (from the momentum table on)
                 const int root_words = (a.do_root_opt && a.n_mlev_root > 0) ? m->h.fk_hdr_words + a.n_mlev_root * m->h.max_width * m->h.fk_rec_words : 0;
                 hp.total_words = m->h.off_fkroot + root_words;
             }
@@ -1363,7 +1367,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         b0.free0p = free0_ordinal_p1(m, kLatG);
         set_hinges_flag(m, b0);
         const bool lean_b = lean_for(b0, kLatG, kLatR, true);
-        const PlanHeader hb = lean_b ? lean_header(b0) : m->h;
+        const PlanHeader hb = lean_b ? lean_header(b0, false) : m->h;
         // Straggler hand-off: chains take very different numbers of iterations (the slowest of 10 000 about 1.6x the
         // mean), so the launch would end on a few waves per CU.  Once all but `hcap` chains are done, the rest move to
         // the latency kernel at their next iteration boundary (QArgs::ctl).

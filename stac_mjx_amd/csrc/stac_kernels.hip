@@ -485,7 +485,7 @@ void q_phase_kernel(const QArgs a_in) {
         //  and the 128-register variants, which have no register left for it, compute them, like everyone beyond the table)
         float spec_tn, spec_beta;
         if constexpr (SPEC == 0 && WPE != 4) {
-            const float2 e = *reinterpret_cast<const float2 *>(lbv - 2 * kTTab + 2 * min(iter, kTTab - 1));
+            const float2 e = *reinterpret_cast<const float2 *>(jrec - 2 * kTTab + 2 * min(iter, kTTab - 1));
             spec_tn = e.x;
             spec_beta = e.y;
             if (__any(iter >= kTTab)) {

@@ -15,7 +15,8 @@ constexpr int kMaxKinds = 40;  // root pass x2 + full + up to 37 part groups
 // registers when K <= kSiteRounds * G (host and kernel evaluate the same condition); else they go through LDS.
 constexpr int kSiteRounds = 3;
 // FISTA's momentum sequence t_0 = 1, t_(k+1) = (1 + sqrt(1 + 4 t_k^2)) / 2 depends on the iteration number alone: the plan holds
-// {t_(k+1), (t_k - 1) / t_(k+1)} for k < kTTab right in front of the lower bounds (PlanHeader::off_lb - 2 kTTab), computed on the host
+// {t_(k+1), (t_k - 1) / t_(k+1)} for k < kTTab right in front of the joint records (PlanHeader::off_joint - 2 kTTab: a launch that
+// wants it stages from there on), computed on the host
 // with the kernel's own float32 expressions; later iterations compute them (stac_kernels.hip)
 constexpr int kTTab = 256;
 // The lean kernels (stac_kernels.hip) take the sites in as many rounds as a rodent-sized marker set needs at their group width
