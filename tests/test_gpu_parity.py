@@ -816,7 +816,7 @@ def test_random_models_bit_exact(seed):
         _compare_phase(res, ref)
 
 
-def _random_lean_case(seed, chains=6, frames=2, maxiter=10):
+def _random_lean_case(seed, chains=6, frames=2, maxiter=10, wide=False):
     """One random model of the kind the lean kernels take (free root, hinges, no oriented body: split kinematics with
     host-scheduled passes -- restarts, bodies / joints without offset, pruned root programs) through every lean launch site,
     each launched twice, against the oracle at tolerance 0.  Returns how many of the launches ran a lean kernel."""
@@ -824,12 +824,20 @@ def _random_lean_case(seed, chains=6, frames=2, maxiter=10):
     from stac_mjx_amd.engine import Engine
     from stac_mjx_amd.mjcf import JNT_FREE
 
-    rng = np.random.default_rng(90000 + seed)
-    nbody = int(rng.integers(3, (25, 45, 70)[seed % 3]))
+    rng = np.random.default_rng((190000 if wide else 90000) + seed)
+    nbody = int(rng.integers(75, 190)) if wide else int(rng.integers(3, (25, 45, 70)[seed % 3]))
     t = _random_tables(rng, nbody, True, p_slide=0.0, p_ball=0.0, max_children_bias=float(rng.choice([0.3, 0.6, 0.9, 0.97])), lean=True,
-                       k_max=int(rng.choice([6, 12, 30])))
-    if t.nq > 80:  # (the lean instantiations hold 80 coordinates at 16 lanes, 96 at 32)
-        pytest.skip("more coordinates than the lean kernels hold")
+                       k_max=int(rng.choice([12, 30, 60]) if wide else rng.choice([6, 12, 30])))
+    if wide:
+        # the wide lean shapes (round 5: 32 lanes, eight solver registers per lane, two rounds of sites): 97 .. 256 coordinates; the
+        # free root's own body may be oriented (a free joint sets its pose: mouse)
+        if not 96 < t.nq <= 256:
+            pytest.skip("not a model of the wide lean shapes")
+        if seed % 2:
+            qr = rng.normal(0, 1, 4)
+            t.body_quat[1] = (qr / np.linalg.norm(qr)).astype(np.float32)
+    elif t.nq > 80:  # (the narrow lean instantiations hold 80 coordinates at 16 lanes, 96 at 32)
+        pytest.skip("more coordinates than the narrow lean kernels hold")
     nq, K = t.nq, t.nsite
     lb, ub = np.full(nq, -np.inf, np.float32), np.full(nq, np.inf, np.float32)
     for j in range(t.njnt):
@@ -854,7 +862,7 @@ def _random_lean_case(seed, chains=6, frames=2, maxiter=10):
     kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=0, root_dims=7, do_root_opt=True)
     ref = orc.ik_clips(kp, lb, ub, part, trunk, 0, 7, do_root_opt=True)
     lean_runs = 0
-    for lanes in (16, 32, 0):
+    for lanes in ((32, 0) if wide else (16, 32, 0)):
         eng = Engine(t, lb, ub, tol=tol, maxiter=maxiter, lanes_per_chain=lanes)
         res = _q_phase_twice(eng, kp, **kw)
         lean_runs += _last_q_kernel(eng)[3] & 1
@@ -868,6 +876,14 @@ def test_random_lean_models_bit_exact(seed):
     """Round 5: random trees of the lean kind (no generator of the other fuzz tests ever draws one: 40 % oriented bodies) -- the
     host's list scheduler of the split kinematics meets chains, bushes, zero offsets and root programs of every shape."""
     _random_lean_case(seed)
+
+
+def test_random_wide_lean_models_bit_exact():
+    """Round 5: random trees of 97 .. 256 coordinates (split-kinematics programs of a hundred steps and more, two rounds of sites,
+    an oriented free-root body in every other one) at 32 lanes and in latency mode, each launched twice, equal to the oracle bit for
+    bit -- and most of them in the wide lean shapes <32,8,2,1> / <32,8,2,9> (a chain deeper than 254 products stays generic)."""
+    lean_runs = sum(_random_lean_case(seed, chains=(5, 40)[seed % 2], frames=1 + seed % 2, wide=True) for seed in range(6))
+    assert lean_runs >= 8, lean_runs  # (two launches per model)
 
 
 def test_random_lean_models_do_take_the_lean_kernels():

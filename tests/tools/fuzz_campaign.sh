@@ -23,6 +23,10 @@ for sw in STAC_HIP_SPEC=0 STAC_HIP_NOFAST=1 STAC_HIP_NOPRUNE=1 "STAC_HIP_QUEUE=8
           "STAC_HIP_SPEC=1 STAC_HIP_SPECG=16" "STAC_HIP_SPEC=1 STAC_HIP_SPECG=16 STAC_HIP_SPECR=8" "STAC_HIP_SPEC=1 STAC_HIP_SPECG=32"; do
   run $NS lean $sw
 done
+run $NS leanwide X=1
+for sw in STAC_HIP_SPEC=0 "STAC_HIP_SPEC=1 STAC_HIP_SPECG=32" STAC_HIP_NOFAST=1; do
+  run $NB leanwide $sw
+done
 echo "== LM" >> $out
 timeout 900 python tests/fuzz_lm_random_models.py $NB 2>&1 | grep -v amdgpu.ids | tail -2 >> $out
 cat $out
