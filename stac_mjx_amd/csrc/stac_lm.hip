@@ -420,10 +420,16 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                 // H[anc_i][p_j] -= l_i H[k][p_j].  Two wave-level syncs and pd(k) divisions per pivot.
                 float *lrow = dv + L.n_max;  // two scratch rows of maxpd floats, used alternately
                 int kprev = -1, pdprev = 0;
+                // (what does not depend on the numbers -- the next pivot's path depth, this lane's first ancestor and pair of either phase --
+                //  is read a phase ahead: the pivots are serial and every dependent LDS round trip of a pivot counts)
+                int pdn = n > 0 ? KT[kh.off_dof + 4 * (n - 1) + 3] : 0;
                 for (int k = n - 1; k >= 0; --k) {
-                    const int pdk = KT[kh.off_dof + 4 * k + 3];
+                    const int pdk = pdn;
+                    pdn = k > 0 ? KT[kh.off_dof + 4 * (k - 1) + 3] : 0;
                     const float *Hk = Hc + k * mp;
                     const float dkk = Hk[pdk];
+                    const int ai0 = anc[k * mp + min(lg, mp - 1)];  // (phase A's first ancestor of this lane)
+                    const int pij0 = TRI[min(lg, ((L.maxpd * (L.maxpd + 1)) >> 1) - 1)];  // (phase B's first pair)
                     if (!(dkk > 0.0f)) bad = true;
                     float *lcur = lrow + (k & 1) * mp;
                     const float *lold = lrow + ((k + 1) & 1) * mp;
@@ -432,14 +438,18 @@ void q_phase_lm_kernel(const QArgs a, const LmArgs L) {
                     for (int p = lg; p < pdk; p += G) {
                         const float l = Hk[p] / dkk;
                         lcur[p] = l;
-                        const int ai = anc[k * mp + p];
+                        const int ai = p == lg ? ai0 : anc[k * mp + p];
                         dv[ai] = FMA(-l, bk, dv[ai]);
                     }
+                    const int pi0 = pij0 >> 8;
+                    const int aj0 = anc[k * mp + min(max(pi0, 0), mp - 1)];  // (phase B's first ancestor: before the fence)
                     wave_sync();
+                    // ((B) dividing H[k][p_i] by the pivot itself instead of waiting for (A)'s quotients -- one fence per pivot -- measured
+                    //  slower: 1.92 against 1.99 M frames/s)
                     const int T = (pdk * (pdk + 1)) >> 1;
                     for (int q = lg; q < T; q += G) {
-                        const int pij = TRI[q], pi = pij >> 8, pj = pij & 0xFF;
-                        const int ai = anc[k * mp + pi];
+                        const int pij = q == lg ? pij0 : TRI[q], pi = pij >> 8, pj = pij & 0xFF;
+                        const int ai = q == lg ? aj0 : anc[k * mp + pi];
                         Hc[ai * mp + pj] = FMA(-lcur[pi], Hk[pj], Hc[ai * mp + pj]);
                     }
                     wave_sync();
