@@ -619,7 +619,7 @@ void q_phase_kernel(const QArgs a_in) {
                 // dependent instructions, which the scheduler interleaves.  A lane whose round has no joint left takes the last
                 // joint again: the same value to the same words.
                 // (throughput kernels: a lone wavefront of the latency kernels pays per instruction, dependent or not)
-                constexpr int U = SPEC != 0 ? 1 : (G == 16 ? 3 : 2);
+                constexpr int U = SPEC != 0 ? (G == 32 ? 2 : 1) : (G == 16 ? 3 : 2);
                 for (int j0 = lg + 1; j0 < H.naj; j0 += U * G) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
