@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void fk3_p3(const int *T3, const int nb, float *CBc, 
     float v0 = slot[0], v1 = slot[12], v2 = slot[24], v3 = slot[36];
     float rl = fk3_restart_value(base, e0);
     float p = 0.0f;
-#pragma unroll 2
+#pragma unroll 2  // (measured 1 / 2 / 4: 554 / 575 / 570 k frames/s, 18.8 / 19.3 / 18.9 k on 40 x 250)
     for (int b = 0; b < nb; ++b) {
         const int e3 = rp[4 * b + 12];
         const float rn = fk3_restart_value(base, e1);  // (before this block's stores: it sees the blocks before this one)

@@ -31,6 +31,10 @@
 #include "stac_plan.hpp"
 #include "stac_device.hpp"
 
+#ifndef STAC_RT
+#define STAC_RT 12  // sites per trip of a latency kernel's range sum (measured 6 / 8 / 12 / 16 / 24: 19.24 / 19.20 / 19.33 / 18.72 / 17.62 k frames/s on 40 x 250)
+#endif
+
 namespace stac {
 
 // ------------------------------------------------------------------------------------------------
@@ -834,12 +838,13 @@ void q_phase_kernel(const QArgs a_in) {
                 // (latency kernels: a lone wavefront waits out every LDS round trip, so eight sites per trip and no remainder loop --
                 //  the sites behind the range's end are read again at its last site and their additions dropped: the same sum)
                 const int last = rr.hi - 1;
-                for (int i = rr.lo; i < rr.hi; i += 8) {
-                    float v[8];
+                constexpr int RT = STAC_RT;
+                for (int i = rr.lo; i < rr.hi; i += RT) {
+                    float v[RT];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = src[kXf * min(i + u, last)];
+                    for (int u = 0; u < RT; ++u) v[u] = src[kXf * min(i + u, last)];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc = i + u <= last ? acc + v[u] : acc;
+                    for (int u = 0; u < RT; ++u) acc = i + u <= last ? acc + v[u] : acc;
                 }
             } else {
                 int i = rr.lo;
