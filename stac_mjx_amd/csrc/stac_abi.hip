@@ -19,6 +19,7 @@ namespace stac {
 bool q_phase_has_variant(int G, int nq, int wpe);
 bool q_phase_has_lean_variant(int G, int nq, int wpe, int spec);
 bool q_phase_lean_conditions(const QArgs &a, int G);
+bool q_phase_lean_holds(int G, int nq, int K);
 hipError_t launch_q_phase(const QArgs &a, int G, int wpb, int wpe, int spec, size_t lds_bytes, hipStream_t s,
                           int *capacity_out, bool lean);
 hipError_t launch_q_phase_lm(const QArgs &a, const LmArgs &L, int G, int wpb, size_t lds_bytes, hipStream_t s,
@@ -53,7 +54,7 @@ static int fail(int code, const std::string &msg) {
 // Developer switches: read from the environment ONCE, at stac_model_create, so that a variable
 // set later cannot change the launch shape of a model in use.  -1 = not set.
 struct DebugSwitches {
-    int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1, stride_add = -1;
+    int flags = -1, spec = -1, specg = -1, specr = -1, wpe = -1, wpb = -1, handoff = -1, queue = -1, stride_add = -1, rsplit = -1;
     bool noprune = false, verbose = false, nofast = false, nofree0 = false, noorder = false, nodiet = false, nolean = false;
     static int geti(const char *name) {
         const char *v = getenv(name);
@@ -61,7 +62,7 @@ struct DebugSwitches {
     }
     void read_env() {
         flags = geti("STAC_HIP_FLAGS"); spec = geti("STAC_HIP_SPEC"); wpe = geti("STAC_HIP_WPE"); wpb = geti("STAC_HIP_WPB");
-        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR"); stride_add = geti("STAC_HIP_STRIDE_ADD");
+        handoff = geti("STAC_HIP_HANDOFF"); queue = geti("STAC_HIP_QUEUE"); specg = geti("STAC_HIP_SPECG"); specr = geti("STAC_HIP_SPECR"); stride_add = geti("STAC_HIP_STRIDE_ADD"); rsplit = geti("STAC_HIP_RSPLIT");
         noprune = getenv("STAC_HIP_NOPRUNE") != nullptr; nofast = getenv("STAC_HIP_NOFAST") != nullptr; nofree0 = getenv("STAC_HIP_NOFREE0") != nullptr; noorder = getenv("STAC_HIP_NOORDER") != nullptr; nolean = getenv("STAC_HIP_NOLEAN") != nullptr; nodiet = getenv("STAC_HIP_NODIET") != nullptr; verbose = getenv("STAC_HIP_VERBOSE") != nullptr;
     }
 };
@@ -421,25 +422,39 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
     const int nab = h3.nab, naj = h3.naj, K = h3.K;
     auto f2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
     auto nz3 = [](const float *v) { return v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f; };
-    // quaternion node of every body (= its last joint, else its parent's) and the pre-joint node of every joint
-    std::vector<int> fin(nab, 0), pre(naj, 0);
+    // Quaternion nodes (entries of the chain's c3_qb array): node j = the quaternion AFTER active joint j (node 0: the free root's, from the
+    // pre-pass), node naj = the sink of idle positions, node naj + 1 + i = the quaternion of the i-th ORIENTED body (body_quat not the
+    // identity, below the root body) before its joints: q_parent * body_quat, the oracle's own order (oracle/stac_oracle.c: fk_chain).
+    // fin[s]: node of body s after its last joint (else its oriented-body node, else its parent's); pre[j]: node in front of joint j.
+    std::vector<int> fin(nab, 0), pre(naj, 0), bnode(nab, -1), bpre(nab, 0);
+    int nbq = 0;
     for (int s = 0; s < nab; ++s) {
         const int ps = m->h_ab_parent[s] - 1;
         int cur = ps >= 0 ? fin[ps] : 0;
+        if (s != 0 && !(m->h_brec[s].flags & 1)) { bpre[s] = cur; bnode[s] = naj + 1 + nbq; cur = bnode[s]; ++nbq; }
         for (int i = 0; i < m->h_ab_jnum[s]; ++i) { const int j = m->h_ab_jadr[s] + i; pre[j] = cur; cur = j; }
         fin[s] = cur;
     }
-    // P1: one product per needed hinge
+    if (nbq != h3.nbq) return false;  // (the layout was made for the model's own count: build_plan)
+    // P1: one product per needed hinge, and one per needed oriented body (its factor: the constant body_quat, which every chain region
+    // holds in c3_bq -- written once per launch, q_phase_kernel's prologue)
+    struct Prod { int qlw, node, prenode; };  // word of the right factor, node of the result, node of the left factor
     std::vector<Fk3Op> o1;
-    std::vector<int> j_of1, op_of_j(naj, -1);
+    std::vector<Prod> p_of1;
+    std::vector<int> op_of_node(naj + 1 + nbq, -1);
     for (int s = 0; s < nab; ++s) {
         if (need && !need[s]) continue;
+        if (bnode[s] >= 0) {
+            op_of_node[bnode[s]] = (int)o1.size();
+            o1.push_back(Fk3Op{bpre[s] == 0 ? -1 : op_of_node[bpre[s]], 0});
+            p_of1.push_back(Prod{h3.c3_bq + 4 * (bnode[s] - naj - 1), bnode[s], bpre[s]});
+        }
         for (int i = 0; i < m->h_ab_jnum[s]; ++i) {
             const int j = m->h_ab_jadr[s] + i;
             if (j == 0) continue;  // the free root: its quaternion comes from the pre-pass
-            op_of_j[j] = (int)o1.size();
-            o1.push_back(Fk3Op{pre[j] == 0 ? -1 : op_of_j[pre[j]], 0});
-            j_of1.push_back(j);
+            op_of_node[j] = (int)o1.size();
+            o1.push_back(Fk3Op{pre[j] == 0 ? -1 : op_of_node[pre[j]], 0});
+            p_of1.push_back(Prod{h3.c3_ql + 4 * j, j, pre[j]});
         }
     }
     // P3: the additions, in the order of the step program (body_pos, then per joint anchor and position)
@@ -475,7 +490,7 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
         }
         body_op[s] = cur;
     }
-    fk3_unshare(o1, 2, [&](int i) { j_of1.push_back(j_of1[i]); });
+    fk3_unshare(o1, 2, [&](int i) { p_of1.push_back(p_of1[i]); });
     fk3_unshare(o3, 4, [&](int i) { rot.push_back(rot[i]); });
     int n1 = fk3_schedule(o1, 2, 3);
     if (n1 > 0) n1 = (n1 + 1) & ~1;  // P1 runs whole blocks of two steps
@@ -504,12 +519,13 @@ static bool build_fk3_program(const stac_model *m, const PlanHeader &h3, const c
             e[0] = e[1] = (int32_t)(0x80000000u | (uint32_t)qbw(0));
         }
     for (size_t i = 0; i < o1.size(); ++i) {
-        const int j = j_of1[i], blk = o1[i].t >> 1, k = o1[i].t & 1, pp = o1[i].pp;
-        T1[24 * blk + 4 * pp + k] = h3.c3_ql + 4 * j;
-        T1[24 * (blk + 1) + 4 * pp + 2 + k] = qbw(j);
+        const Prod &pr = p_of1[i];
+        const int blk = o1[i].t >> 1, k = o1[i].t & 1, pp = o1[i].pp;
+        T1[24 * blk + 4 * pp + k] = pr.qlw;
+        T1[24 * (blk + 1) + 4 * pp + 2 + k] = qbw(pr.node);
         if (o1[i].restart) {  // (only in the first step of a block: fk3_schedule)
-            T1[24 * blk + 16 + 2 * pp + 1] = qbw(pre[j]);
-            T1[24 * (blk + 1) + 16 + 2 * pp] = qbw(pre[j]);
+            T1[24 * blk + 16 + 2 * pp + 1] = qbw(pr.prenode);
+            T1[24 * (blk + 1) + 16 + 2 * pp] = qbw(pr.prenode);
         }
     }
     for (int i = 0; i < cap2; ++i) { T2[4 * i + 3] = qbw(0) | (h3.c3_pb + 3 * sink_slot) << 16; }  // no-op: rotate(0, root quaternion) into the sink
@@ -722,6 +738,21 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
         if (ranges.empty()) ranges.push_back(RangeRec{0, 0});
     }
     h.nrange = (int)ranges.size();
+    {   // PlanHeader::rsplit: how many of the longest ranges the 16-lane kernels sum one component per lane.  Cost of a choice, in
+        // instructions of the wavefront (every round of lanes is as long as its longest loop): a site of a component task is one read and
+        // one addition, of a whole range six of each; a round has a fixed part (its record, the stores, the loop).
+        auto cost = [&](int ns) {
+            const double c1 = 2.5, c6 = 13.0, fixed = 15.0;
+            double c = 0.0;
+            for (int t0 = 0; t0 < 6 * ns; t0 += 16) c += fixed + c1 * (ranges[t0 / 6].hi - ranges[t0 / 6].lo);  // (sorted: a round's first task is its longest)
+            for (int r0 = ns; r0 < h.nrange; r0 += 16) c += fixed + c6 * (ranges[r0].hi - ranges[r0].lo);
+            return c;
+        };
+        int best = 0;
+        for (int ns = 1; ns <= h.nrange; ++ns)
+            if (cost(ns) < cost(best)) best = ns;
+        h.rsplit = m->dbg.rsplit >= 0 ? std::min(m->dbg.rsplit, h.nrange) : best;
+    }
     std::vector<JointRec> jrec(std::max(naj, 1));
     int nqj = 0;
     for (int j = 0; j < naj; ++j) {
@@ -814,28 +845,32 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
     {   // Split kinematics (PlanHeader::fk3; stac_plan.hpp): a free root at qpos 0 .. 6 on the ONE top-level active body, hinges
         // below it, no oriented body.  The lean kernels run nothing else, so a model without it takes the generic kernels.
         h.fk3 = 0;
-        // (the free root's own body may be oriented: a free joint sets the body's pose, body_pos / body_quat do not enter -- mouse)
-        bool bquat_below = false;
-        for (int s2 = 1; s2 < nab; ++s2) bquat_below = bquat_below || !(brec[s2].flags & 1);
-        bool ok = naj >= 1 && aj_type[0] == STAC_JNT_FREE && aj_qadr[0] == 0 && ab_jnum[0] >= 1 && ab_jadr[0] == 0 && !bquat_below && nqj == 1 && !has_ball &&
-                  getenv("STAC_HIP_NOFK3") == nullptr;
+        // (the free root's own body may be oriented: a free joint sets the body's pose, body_pos / body_quat do not enter -- mouse;
+        //  an oriented body below it is one more product of P1, q_parent * body_quat, with the constant as its right factor -- fly)
+        std::vector<float> bq_const;
+        for (int s2 = 1; s2 < nab; ++s2)
+            if (!(brec[s2].flags & 1)) bq_const.insert(bq_const.end(), brec[s2].quat, brec[s2].quat + 4);
+        const int nbq = (int)bq_const.size() / 4;
+        bool ok = naj >= 1 && aj_type[0] == STAC_JNT_FREE && aj_qadr[0] == 0 && ab_jnum[0] >= 1 && ab_jadr[0] == 0 && nqj == 1 && !has_ball &&
+                  getenv("STAC_HIP_NOFK3") == nullptr && !(nbq > 0 && getenv("STAC_HIP_NOFK3BQ") != nullptr);
         for (int j = 1; j < naj && ok; ++j) ok = aj_type[j] == STAC_JNT_HINGE;
         for (int s = 1; s < nab && ok; ++s) ok = ab_parent[s] != 0;
         if (ok) {
             PlanHeader g = h;  // the lean chain layout: regions of whole 4-word groups, stride 4 x odd (16-byte aligned entries)
             // capacities of a program area: the full program's own sizes (a pruned program is a sub-DAG: it is checked against them)
             Fk3Program probe;
-            g.c3_qb = 0; g.c3_pb = 0; g.c3_ql = 0; g.stride3 = 1;
+            g.c3_qb = 0; g.c3_pb = 0; g.c3_ql = 0; g.c3_bq = 0; g.nbq = nbq; g.stride3 = 1;
             ok = build_fk3_program(m, g, nullptr, 254, 4096, 252, probe);
             if (ok) {
                 // (cap1 even, >= 10: the table area 16 (cap1 + 2) holds cap1 / 2 + 3 records of 24 words; cap3: whole blocks)
                 g.fk3_cap1 = std::max(probe.n1, 10); g.fk3_cap2 = std::max(probe.n2, 32); g.fk3_cap3 = std::max(probe.n3, 4);
                 int o3 = 0;
-                g.c3_qb = o3; o3 += (naj + 1) * 4;                       // (+ 1: the sink of idle P1 positions)
+                g.c3_qb = o3; o3 += (naj + 1 + nbq) * 4;                 // (+ 1: the sink of idle P1 positions; then the oriented bodies' nodes)
                 g.c3_pb = o3; o3 += ((g.fk3_cap3 * 4 + 4) * 3 + 3) & ~3;  // (step, position) slots, root position, sink, slack of the prefetch
                 g.c3_ql = o3; o3 += std::max(naj * 4, (h.nrange * kXf + 3) & ~3);
                 g.c_rw = g.c3_ql;                                         // a full trip's range sums go where the joint-local quaternions were
                 g.c3_rw0 = o3; o3 += 8;
+                g.c3_bq = o3; o3 += 4 * nbq;                              // body_quat (w, x, y, z) of the oriented bodies: constants, written by the prologue
                 g.c_jn = o3; o3 += 4;
                 g.c_qsv = o3; o3 += 4 * nqj;
                 g.c_sw = o3; o3 += (std::max(K * kXf, h.nqpad + kXf) + 3) & ~3;
@@ -852,6 +887,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                 if (ok) {
                     g.fk3 = 1;
                     g.fk3_n = full.n1 | full.n3 << 8 | full.n2 << 16;
+                    g.off3_bq = put_raw(bq_const.data(), bq_const.size());
                     g.off3_prog = put_raw(full.words.data(), full.words.size());
                     g.off3_site = g.off3_prog + 16 * (g.fk3_cap1 + 2) + 4 * g.fk3_cap2 + 4 * g.fk3_cap3;
                     std::vector<int32_t> blank3(full.words.size(), 0);
@@ -862,6 +898,7 @@ static int build_plan(stac_model *m, const stac_model_tables *t) {
                     h.fk3 = keep[0]; h.off3_site = keep[1]; h.off3_prog = keep[2]; h.off3_root = keep[3]; h.fk3_n = keep[4];
                     h.fk3_cap1 = keep[5]; h.fk3_cap2 = keep[6]; h.fk3_cap3 = keep[7];
                     h.c3_ql = g.c3_ql; h.c3_qb = g.c3_qb; h.c3_pb = g.c3_pb; h.c3_rw0 = g.c3_rw0; h.stride3 = g.stride3;
+                    h.c3_bq = g.c3_bq; h.off3_bq = g.off3_bq; h.nbq = g.nbq;
                     m->h3 = g;
                 }
             }
@@ -906,7 +943,7 @@ static void rebase_plan_offsets(PlanHeader &h) {
     const int sk = h.plan_skip;
     if (sk <= 0) return;
     int32_t *offs[] = {&h.off_joint, &h.off_site, &h.off_range, &h.off_lb, &h.off_ub, &h.off_qpos0, &h.off_quat_adr,
-                       &h.off_active, &h.off_fkstep, &h.off_fkroot, &h.off3_site, &h.off3_prog, &h.off3_root};
+                       &h.off_active, &h.off_fkstep, &h.off_fkroot, &h.off3_site, &h.off3_prog, &h.off3_root, &h.off3_bq};
     for (int32_t *o : offs) *o -= sk;
     h.off_lev_adr = h.off_body = 0;  // not staged (nothing of a program launch reads them)
 }
@@ -1153,11 +1190,14 @@ static int pick_lanes(const stac_model *m, const PlanHeader *lean_h, int request
     //  on --, or null when the call cannot be lean.  Every candidate width is sized with the header ITS launch would get: the lean one
     //  where a lean instantiation holds nq at that width, the generic one elsewhere (mouse: lean at 32 lanes only))
     const int nq = m->h.nq;
-    auto thr_lean = [&](int G) { return lean_h && (q_phase_has_lean_variant(G, nq, 2, 0) || q_phase_has_lean_variant(G, nq, 3, 0)); };
+    // (a lean width must also hold the model's sites in registers -- what q_phase_lean_conditions will ask of the launch --: else the width
+    //  would be sized with a header the launch does not get)
+    const int K = m->h.K;
+    auto thr_lean = [&](int G) { return lean_h && q_phase_lean_holds(G, nq, K) && (q_phase_has_lean_variant(G, nq, 2, 0) || q_phase_has_lean_variant(G, nq, 3, 0)); };
     auto thr_shape = [&](int G) { const bool ln = thr_lean(G); return pick_shape(ln ? *lean_h : m->h, G, nkinds, -1, ln); };
     PlanHeader lean_spec = lean_h ? *lean_h : m->h;  // (a lean latency launch stages from the joint records on: no momentum table)
     if (lean_h) lean_spec.plan_skip += 2 * kTTab;
-    auto spec_hdr = [&](int G, int nr) -> const PlanHeader & { return lean_h && q_phase_has_lean_variant(G, nq, 2, nr) ? lean_spec : m->h; };
+    auto spec_hdr = [&](int G, int nr) -> const PlanHeader & { return lean_h && q_phase_lean_holds(G, nq, K) && q_phase_has_lean_variant(G, nq, 2, nr) ? lean_spec : m->h; };
     if (requested == 4 || requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
     if (spec_allowed) {
         const SpecShape ss = lat_one_wave_ok(m->h) ? pick_spec_shape(spec_hdr(kLatG, kLatR), kLatG, nkinds, -1, kLatR)  // one chain per wave
@@ -1259,7 +1299,7 @@ static int run_q(const stac_model *mc, const stac_q_params *p, QArgs &a, int nch
         // (measured, rodent, 250-frame clips: DESIGN.md 2.1), else one wavefront per chain
         int sg = kLatG;
         {
-            const bool l32 = likely_lean && q_phase_has_lean_variant(32, m->h.nq, 2, 8);
+            const bool l32 = likely_lean && q_phase_lean_holds(32, m->h.nq, m->h.K) && q_phase_has_lean_variant(32, m->h.nq, 2, 8);
             const SpecShape s64 = pick_spec_shape(m->h, 64, nkinds), s32 = pick_spec_shape(l32 ? lean_header(a, false) : m->h, 32, nkinds);
             if (s64.resident && (long)nchains <= kSpec64MaxChains) sg = 64;
             else if (s32.resident && (long)nchains <= kSpec32MaxChains) sg = 32;

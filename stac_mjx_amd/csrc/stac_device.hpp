@@ -155,7 +155,7 @@ enum PinClass { PIN_N = 0, PIN_S = 1, PIN_V = 2, PIN_C = 3 };
     X(c_qe, STAC_PIN_ADDR) X(c_qsv, STAC_PIN_ADDR) X(chain_stride, STAC_PIN_ADDR)                                              \
     X(c3_ql, STAC_PIN_ADDR) X(c3_qb, STAC_PIN_ADDR) X(c3_pb, STAC_PIN_ADDR) X(c3_rw0, STAC_PIN_ADDR) X(off3_prog, STAC_PIN_ADDR) \
     X(off3_root, STAC_PIN_ADDR) X(off3_site, STAC_PIN_ADDR) X(fk3_n, STAC_PIN_CTL2) \
-    X(fk3_cap1, STAC_PIN_CTL2) X(fk3_cap2, STAC_PIN_CTL2) X(fk3_cap3, STAC_PIN_CTL2)
+    X(fk3_cap1, STAC_PIN_CTL2) X(fk3_cap2, STAC_PIN_CTL2) X(fk3_cap3, STAC_PIN_CTL2) X(rsplit, STAC_PIN_CTL)
 #define STAC_HOT_ARGS_FIELDS(X)                                                                                                \
     X(single, STAC_PIN_CTL) X(P, STAC_PIN_CTL2) X(flags, STAC_PIN_CTL) X(free0p, STAC_PIN_CTL) X(root_fast, STAC_PIN_CTL)       \
     X(n_mlev_root, STAC_PIN_CTL2) X(n_run_root, STAC_PIN_CTL2) X(n_root_joints, STAC_PIN_CTL2) X(maxls, STAC_PIN_CTL)           \
@@ -173,6 +173,7 @@ struct HotHeader {  // PlanHeader fields of every trip (values)
     int32_t nq, K, nqpad, naj, nrange, max_width, off_joint, off_site, off_lb, off_ub, off_range, off_fkstep, off_fkroot, fk_hdr_words,
         n_mlev_hdr, n_mlev, fk_rec_words, fk_uniform, c_bx, c_ja, c_jn, c_sw, c_sink, c_rw, c_qe, c_qsv, chain_stride;
     int32_t c3_ql, c3_qb, c3_pb, c3_rw0, off3_prog, off3_root, off3_site, fk3_n, fk3_cap1, fk3_cap2, fk3_cap3;  // split kinematics
+    int32_t rsplit;
 };
 template <int VPIN, class KH>
 __device__ __forceinline__ HotHeader pin_header(const KH &h) {  // before the loop: the pinned ones
@@ -185,7 +186,7 @@ __device__ __forceinline__ HotHeader pin_header(const KH &h) {  // before the lo
 struct TripHeader : HotHeader {  // + the other PlanHeader fields (references into the kernarg segment)
     KRef<int32_t> nbody, njnt, nab, nlev, nquat, has_ball, off_lev_adr, off_body, off_qpos0, off_quat_adr, off_active, total_words,
         plan_skip, core_words, c_gg, c_kp, c_r2, stride_regs, stride_lds, stride_forced, nst, nqj, kpow2;
-    KRef<int32_t> fk3, stride3;
+    KRef<int32_t> fk3, stride3, nbq, c3_bq, off3_bq;
 };
 template <int VPIN, class KH>
 __device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH &k) {  // inside the loop: pinned values + fresh reads
@@ -196,9 +197,9 @@ __device__ __forceinline__ TripHeader trip_header(const HotHeader &hot, const KH
     return TripHeader{t, k.nbody, k.njnt, k.nab, k.nlev, k.nquat, k.has_ball, k.off_lev_adr, k.off_body, k.off_qpos0, k.off_quat_adr,
                       k.off_active, k.total_words, k.plan_skip, k.core_words, k.c_gg, k.c_kp, k.c_r2, k.stride_regs, k.stride_lds,
                       k.stride_forced, k.nst, k.nqj, k.kpow2,
-                      k.fk3, k.stride3};
+                      k.fk3, k.stride3, k.nbq, k.c3_bq, k.off3_bq};
 }
-static_assert(sizeof(PlanHeader) == (27 + 15 + 19 + 2) * 4, "TripHeader must list every PlanHeader field");
+static_assert(sizeof(PlanHeader) == (27 + 15 + 19 + 2 + 1 + 3) * 4, "TripHeader must list every PlanHeader field");
 struct HotArgs {  // QArgs fields of every trip (values)
     int32_t single, P, flags, free0p, root_fast, n_mlev_root, n_run_root, n_root_joints, maxls, maxiter, queue_slots, resume;
     uint32_t root_trunk_lo, root_trunk_hi;

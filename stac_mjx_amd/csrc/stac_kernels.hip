@@ -230,6 +230,9 @@ void q_phase_kernel(const QArgs a_in) {
 
     // bx[0] = world (the lean kernels' split kinematics have no world entry)
     if (!LEAN && lg == 0) { st_tpos(bx, V3{0.f, 0.f, 0.f}); st_tquat(bx, Q4{1.f, 0.f, 0.f, 0.f}); }
+    // lean: the oriented bodies' constant quaternions, the right factors of their products in P1 (PlanHeader::nbq; once per launch --
+    // nothing else writes the region)
+    if constexpr (LEAN) { for (int i = lg; i < 4 * H.nbq; i += G) CB[H.c3_bq + i] = P[H.off3_bq + i]; }
 
     // initial qpos, keypoints of frame 0, first solve
     size_t kp_chain = (size_t)(chain < a.C ? chain : 0) * a.F * 3 * K;
@@ -862,7 +865,13 @@ void q_phase_kernel(const QArgs a_in) {
                     const float v0 = src[kXf * i], v1 = src[kXf * (i + 1)], v2 = src[kXf * (i + 2)], v3 = src[kXf * (i + 3)];
                     acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
                 }
-                for (; i < rr.hi; ++i) acc = acc + src[kXf * i];
+                if (i < rr.hi) {  // the last one to three sites in one trip (as range_sum)
+                    const int last = rr.hi - 1;
+                    const float v0 = src[kXf * i], v1 = src[kXf * min(i + 1, last)], v2 = src[kXf * min(i + 2, last)];
+                    acc = acc + v0;
+                    acc = i + 1 <= last ? acc + v1 : acc;
+                    acc = i + 2 <= last ? acc + v2 : acc;
+                }
             }
             CBx[H.c_rw + kXf * r + co] = acc;
         };
@@ -968,6 +977,13 @@ void q_phase_kernel(const QArgs a_in) {
             // the range sums go where the body transforms were (the site pass, their last reader, is over; cref is in a
             // register), the gradient where the site wrenches were (dead once the range sums are done)
             if constexpr (G >= 32) { for (int t = lg; t < 6 * H.nrange; t += G) range_task(t, CB); }
+            else if constexpr (LEAN && SPEC == 0 && G == 16) {
+                // the longest ranges one component per lane, the others one range per lane (PlanHeader::rsplit: the rodent's 23-site
+                // range of the root joint is 23 reads and additions on each of six lanes instead of 138 of each on one)
+                const int ns = H.rsplit;
+                for (int t = lg; t < 6 * ns; t += G) range_task(t, CB);
+                for (int r = ns + lg; r < H.nrange; r += G) range_sum(r, CB);
+            }
             else { for (int r = lg; r < H.nrange; r += G) range_sum(r, CB); }
             wave_sync();
             if constexpr (SPEC != 0) {  // (latency kernels: the bootstrap evaluation of a solve is rare; they keep the zeroed vector)
@@ -1787,12 +1803,22 @@ bool q_phase_has_lean_variant(int G, int nq, int wpe, int spec) {
 // hinges below a free root at qpos 0 .. 6 (QArgs::flags == 16: set_hinges_flag, no developer flag), the split kinematics
 // (PlanHeader::fk3: stac_plan.hpp), every site in registers at this group width.  The host decides with it which chain layout
 // the launch gets (run_q) and passes its decision to launch_q_phase.
-bool q_phase_lean_conditions(const QArgs &a, int G) {
-    int nqr = 0;  // solver registers per lane of the lean instantiation that holds nq at this width (the same for every register cap / role count)
-#define STAC_NQR(GG, RR, WW) if (G == GG && a.h.nq <= GG * RR && (nqr == 0 || RR < nqr)) nqr = RR;
+// solver registers per lane of the lean instantiation that holds nq at this width (the same for every register cap / role count); 0: none
+int q_phase_lean_nqr(int G, int nq) {
+    int nqr = 0;
+#define STAC_NQR(GG, RR, WW) if (G == GG && nq <= GG * RR && (nqr == 0 || RR < nqr)) nqr = RR;
     STAC_Q_LEAN_SHAPES(STAC_NQR)
     STAC_Q_SPEC_LEAN_SHAPES(STAC_NQR)
 #undef STAC_NQR
+    return nqr;
+}
+// ... and does it hold the model's K sites in registers?  (what the width heuristics of the host need to know before a launch exists)
+bool q_phase_lean_holds(int G, int nq, int K) {
+    const int nqr = q_phase_lean_nqr(G, nq);
+    return nqr > 0 && K <= lean_site_rounds(G, nqr) * G;
+}
+bool q_phase_lean_conditions(const QArgs &a, int G) {
+    const int nqr = q_phase_lean_nqr(G, a.h.nq);
     return !a.single && !a.bounds && a.flags == 16 && a.free0p == 1 && a.h.fk3 == 1 && nqr > 0 && a.h.K <= lean_site_rounds(G, nqr) * G &&
            a.h.nqj == 1 && !a.h.has_ball && G >= 16;
 }

@@ -197,6 +197,13 @@ struct PlanHeader {
     int32_t c3_pb;         // [(cap3 * 4 + 4) * 3] position slots by (step, position) of P3; then the root position, a sink, slack
     int32_t c3_rw0;        // [kXf] range sum of the root joint in a root fast trip (which keeps c3_ql intact)
     int32_t stride3;       // chain stride of a lean launch (odd)
+    int32_t nbq, c3_bq, off3_bq;  // oriented bodies below the root body (body_quat not the identity): how many; their constant quaternions
+                           // (w, x, y, z) in a chain's region (the right factors of their products in P1; written once, by the prologue);
+                           // the same in the blob
+    // Range sums by component (16 lanes per chain): the first rsplit of the distinct site ranges (they are sorted longest first) are
+    // summed one COMPONENT {F.x .. T.z} per lane -- the same left-to-right sums, a sixth of the serial length --, the others one range
+    // per lane as before.  The host picks the split that makes the two passes shortest (build_plan); 0 = every range whole.
+    int32_t rsplit;
 };
 
 // Full-model tables for the stand-alone FK / offset-phase kernels (device pointers).

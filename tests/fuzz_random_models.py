@@ -25,12 +25,14 @@ if os.environ.get("STAC_FUZZ_POISON"):
     _E.Engine.q_phase = _poisoned
 bad = 0; ran = 0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # `N big`: the large-tree / many-chain flavour (test_random_models_large_trees_many_chains)
-lean = len(sys.argv) > 2 and sys.argv[2] in ("lean", "leanwide")  # `N lean`: trees of the lean kernels' kind (split kinematics), several chain counts
-wide = len(sys.argv) > 2 and sys.argv[2] == "leanwide"  # `N leanwide`: 97 .. 256 coordinates (the wide lean shapes)
+lean = len(sys.argv) > 2 and sys.argv[2] in ("lean", "leanwide", "leanbq", "leanwidebq")  # `N lean`: trees of the lean kernels' kind (split kinematics), several chain counts
+wide = len(sys.argv) > 2 and sys.argv[2] in ("leanwide", "leanwidebq")  # `N leanwide`: 97 .. 256 coordinates (the wide lean shapes)
+bq = len(sys.argv) > 2 and sys.argv[2].endswith("bq")  # `N leanbq` / `N leanwidebq`: with oriented bodies below the root (round 6: the fly's kind)
 for seed in range(12, 12 + int(sys.argv[1])):
     try:
         if lean:
-            T._random_lean_case(seed, chains=int((5, 40, 300)[seed % 3]), frames=1 + seed % 3, wide=wide)
+            T._random_lean_case(seed, chains=int((5, 40, 300)[seed % 3]), frames=1 + seed % 3, wide=wide,
+                                p_oriented=(0.15, 0.4, 0.7)[(seed // 3) % 3] if bq else None)
         elif big:
             T._random_model_case(seed, 40, 110, int((7, 70, 300)[seed % 3]), 1 + seed % 3, (8, 16, 32, 64, 0), q_init=bool(seed % 2))
         else:

@@ -689,11 +689,11 @@ def test_lm_chain_queue_same_as_static_assignment(rodent_setup, rodent_mocap, mo
 
 
 # ---- random models: the plan builder (levels, positions, stored transforms, step program) on arbitrary trees ------------
-def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_bias=0.6, lean=False, k_max=12):
+def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_bias=0.6, lean=False, k_max=12, p_oriented=None):
     """A random kinematic tree as ModelTables: depth-first body order, 0-3 joints per body (mostly hinges, some with
     jnt_pos == 0, some slides / balls), random body orientations (some identity), sites on random bodies.
-    lean: what the lean kernels' split kinematics take -- no oriented body, only hinges below the (free) root; some bodies
-    with body_pos == 0."""
+    lean: what the lean kernels' split kinematics take -- only hinges below the (free) root; some bodies with body_pos == 0;
+    oriented bodies only on request (p_oriented: round 6 -- one more product of the quaternion pass each)."""
     from stac_mjx_amd.mjcf import JNT_BALL, JNT_FREE, JNT_HINGE, JNT_SLIDE, ModelTables
 
     parent = [0] * nbody
@@ -714,7 +714,7 @@ def _random_tables(rng, nbody, free_root, p_slide=0.1, p_ball=0.0, max_children_
     body_pos = rng.normal(0, 0.05, (nbody, 3))
     body_quat = np.tile([1.0, 0, 0, 0], (nbody, 1))
     for b in range(1, nbody):
-        if not lean and rng.random() < 0.4:
+        if (not lean and rng.random() < 0.4) if p_oriented is None else (rng.random() < p_oriented):
             body_quat[b] = unit(rng.normal(0, 1, 4))
         if lean and rng.random() < 0.15:
             body_pos[b] = 0.0
@@ -816,7 +816,7 @@ def test_random_models_bit_exact(seed):
         _compare_phase(res, ref)
 
 
-def _random_lean_case(seed, chains=6, frames=2, maxiter=10, wide=False):
+def _random_lean_case(seed, chains=6, frames=2, maxiter=10, wide=False, p_oriented=None):
     """One random model of the kind the lean kernels take (free root, hinges, no oriented body: split kinematics with
     host-scheduled passes -- restarts, bodies / joints without offset, pruned root programs) through every lean launch site,
     each launched twice, against the oracle at tolerance 0.  Returns how many of the launches ran a lean kernel."""
@@ -824,10 +824,10 @@ def _random_lean_case(seed, chains=6, frames=2, maxiter=10, wide=False):
     from stac_mjx_amd.engine import Engine
     from stac_mjx_amd.mjcf import JNT_FREE
 
-    rng = np.random.default_rng((190000 if wide else 90000) + seed)
+    rng = np.random.default_rng((190000 if wide else 90000) + seed + (200000 if p_oriented else 0))
     nbody = int(rng.integers(75, 190)) if wide else int(rng.integers(3, (25, 45, 70)[seed % 3]))
     t = _random_tables(rng, nbody, True, p_slide=0.0, p_ball=0.0, max_children_bias=float(rng.choice([0.3, 0.6, 0.9, 0.97])), lean=True,
-                       k_max=int(rng.choice([12, 30, 60]) if wide else rng.choice([6, 12, 30])))
+                       k_max=int(rng.choice([12, 30, 60]) if wide else rng.choice([6, 12, 30])), p_oriented=p_oriented)
     if wide:
         # the wide lean shapes (round 5: 32 lanes, eight solver registers per lane, two rounds of sites): 97 .. 256 coordinates; the
         # free root's own body may be oriented (a free joint sets its pose: mouse)
@@ -888,6 +888,18 @@ def test_random_wide_lean_models_bit_exact():
 
 def test_random_lean_models_do_take_the_lean_kernels():
     assert sum(_random_lean_case(s) for s in (100, 101, 102)) >= 6  # (three launches per model)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_lean_models_with_oriented_bodies_bit_exact(seed):
+    """Round 6: an oriented body below the root (body_quat not the identity: the fruit fly's legs) is one more product of the
+    quaternion pass, q_parent * body_quat, its right factor a constant that every chain region holds -- random trees in which 15 to
+    60 % of the bodies are oriented, through every lean launch site, against the oracle at tolerance 0."""
+    _random_lean_case(seed, p_oriented=(0.15, 0.4, 0.6)[seed % 3])
+
+
+def test_random_oriented_lean_models_do_take_the_lean_kernels():
+    assert sum(_random_lean_case(s, p_oriented=0.4) for s in (100, 101, 102)) >= 6  # (three launches per model)
 
 
 def _random_model_case(seed, nbody_lo, nbody_hi, chains, frames, lanes_list, maxiter=10, q_init=False):
@@ -1317,6 +1329,46 @@ def test_default_launches_of_the_mouse_take_the_wide_lean_kernels(mouse_setup):
     np.testing.assert_array_equal(_np(big["qpos"])[:4].view(np.uint32), ref1["qpos"].view(np.uint32))
     np.testing.assert_array_equal(_np(big["qpos"])[2996:].view(np.uint32), ref1["qpos"].view(np.uint32))
     _compare_phase(few, orc.ik_clips(kp4.reshape(2, 2, -1), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, fs.root_kp_idx, fs.root_dims, do_root_opt=fs.do_root_opt))
+
+
+def test_default_launches_of_the_fly_take_the_lean_kernels(fly_setup, monkeypatch):
+    """Round 6: BASELINE configs[4]'s model (fruit fly: 24 oriented leg bodies, a free root that is not optimised -- tethered) runs the
+    split kinematics by the host's own choice at every launch site, equals the oracle there, and equals the generic kernels'
+    bits (STAC_HIP_NOFK3BQ: no split-kinematics tables for a model with oriented bodies, as before round 6)."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine
+
+    fs = fly_setup
+    t = fs.tables
+    orc = Oracle(t, tol=5e-3, maxiter=12)
+    rng = np.random.default_rng(21)
+    qt = t.qpos0[None] + np.clip(rng.normal(0, 0.15, (8, t.nq)), -0.3, 0.3).astype(np.float32)
+    qt[:, 3:7] = t.qpos0[3:7]
+    kp8 = np.stack([orc.fk(q)["site_xpos"].reshape(-1) for q in qt]).astype(np.float32)
+    kp8 = (kp8 + rng.normal(0, 1e-3, kp8.shape)).astype(np.float32)
+    kw = dict(part_masks=fs.part_masks)
+    okw = dict(do_root_opt=False)
+    eng = Engine(t, fs.lb, fs.ub, tol=5e-3, maxiter=12)
+    big = eng.q_phase(np.tile(kp8, (750, 1)).reshape(6000, 1, -1), **kw)  # throughput launch (+ hand-off)
+    g, nqr, wpe, specp = _last_q_kernel(eng)
+    assert g == 16 and specp & 1, (g, nqr, wpe, specp)
+    few = _q_phase_twice(eng, kp8.reshape(4, 2, -1), **kw)                 # latency launch
+    assert _last_q_kernel(eng)[3] & 1 and _last_q_kernel(eng)[3] & ~1, _last_q_kernel(eng)
+    ref1 = orc.ik_clips(kp8.reshape(8, 1, -1), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 0, 7, **okw)
+    np.testing.assert_array_equal(_np(big["qpos"])[:8].view(np.uint32), ref1["qpos"].view(np.uint32))
+    np.testing.assert_array_equal(_np(big["qpos"])[5992:].view(np.uint32), ref1["qpos"].view(np.uint32))
+    _compare_phase(few, orc.ik_clips(kp8.reshape(4, 2, -1), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 0, 7, **okw))
+    eng16 = Engine(t, fs.lb, fs.ub, tol=5e-3, maxiter=12, lanes_per_chain=16)
+    thr = _q_phase_twice(eng16, kp8.reshape(4, 2, -1), **kw)                # throughput kernel on request
+    assert _last_q_kernel(eng16)[0] == 16 and _last_q_kernel(eng16)[3] == 1
+    _compare_phase(thr, orc.ik_clips(kp8.reshape(4, 2, -1), fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 0, 7, **okw))
+    monkeypatch.setenv("STAC_HIP_NOFK3BQ", "1")
+    gen = Engine(t, fs.lb, fs.ub, tol=5e-3, maxiter=12)
+    gbig = gen.q_phase(np.tile(kp8, (750, 1)).reshape(6000, 1, -1), **kw)
+    assert not (_last_q_kernel(gen)[3] & 1)
+    for key in ("qpos", "frame_error", "counters"):
+        a, b = _np(big[key]), _np(gbig[key])
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), key
 
 
 @pytest.mark.parametrize("model,lanes,solver,env", _SHAPE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else
