@@ -1230,9 +1230,15 @@ void q_phase_kernel(const QArgs a_in) {
                     const int ll = lane % LC;
                     const V3 crefa = LEAN ? ld3(CBa + root_w) : ld_tpos(CBa + H.c_bx + kXf), crefn = LEAN ? ld3(CBn + root_w) : ld_tpos(CBn + H.c_bx + kXf);
                     for (int e = ll; e < nqpad; e += LC) { gxa[e] = 0.0f; gxn[e] = 0.0f; }
-                    for (int i = ll; i < 2 * H.nrange; i += LC) {
-                        const bool nx = i >= H.nrange;
-                        range_sum(nx ? i - H.nrange : i, nx ? CBn : CBa);
+                    // (the longest ranges one component per lane, as in the throughput kernels: PlanHeader::rsplit)
+                    const int nt = 6 * H.rsplit, nw = H.nrange - H.rsplit;
+                    for (int i = ll; i < 2 * nt; i += LC) {
+                        const bool nx = i >= nt;
+                        range_task(nx ? i - nt : i, nx ? CBn : CBa);
+                    }
+                    for (int i = ll; i < 2 * nw; i += LC) {
+                        const bool nx = i >= nw;
+                        range_sum(H.rsplit + (nx ? i - nw : i), nx ? CBn : CBa);
                     }
                     wave_sync();
                     for (int i = ll; i < 2 * H.naj; i += LC) {
@@ -1765,8 +1771,10 @@ static hipError_t launch_q(const QArgs &a, int wpb, size_t lds_bytes, hipStream_
 #define STAC_Q_SPEC_SHAPES(X) X(16, 5, 4) X(32, 3, 8)
 #else
 // lean kernels (SPECP bit 0): the shapes that rodent-sized models run in -- large batches, the straggler hand-off, few long clips
-#define STAC_Q_LEAN_SHAPES(X) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2) X(32, 8, 2)
-#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 5, 4) X(16, 5, 8) X(32, 3, 8) X(32, 8, 8)
+// (the first shape of a width that holds nq is taken: narrower ones first.  Three solver registers per lane at 16 lanes, two at 32: models of
+//  up to 48 / 64 coordinates -- the fruit fly's 43 --, whose nq-sums and staging then run over three registers instead of five)
+#define STAC_Q_LEAN_SHAPES(X) X(16, 3, 3) X(16, 5, 2) X(16, 5, 3) X(32, 3, 2) X(32, 8, 2)
+#define STAC_Q_SPEC_LEAN_SHAPES(X) X(16, 3, 4) X(16, 5, 4) X(16, 5, 8) X(32, 2, 8) X(32, 3, 8) X(32, 8, 8)
 #define STAC_Q_SHAPES(X)                                                        \
     X(8, 10, 2) X(8, 16, 2)                                                      \
     X(16, 5, 2) X(16, 5, 3) X(16, 8, 2) X(16, 8, 3) X(16, 16, 2)                 \

@@ -1217,6 +1217,9 @@ _SHAPE_CASES = [
     ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),         # q<32,8,2,9>  (lean)
     ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32", "STAC_HIP_NOLEAN": "1"}),   # q<32,8,2,8>  (generic)
     ("mouse", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "64"}),         # q<64,4,2,8>
+    ("fly", 16, "pg", {"STAC_HIP_WPE": "3"}),                                   # q<16,3,3,1>  (lean: the narrow shapes of models up to 48 / 64 coordinates)
+    ("fly", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "16"}),           # q<16,3,2,5>
+    ("fly", 0, "pg", {"STAC_HIP_SPEC": "1", "STAC_HIP_SPECG": "32"}),           # q<32,2,2,9>
     ("rodent", 16, "lm", {}), ("rodent", 32, "lm", {}), ("rodent", 64, "lm", {}),     # lm<16,5,2> lm<32,3,2> lm<64,2,3>
     ("mid", 16, "lm", {}),                                                      # lm<16,8,2>
     ("big", 16, "lm", {}), ("big", 32, "lm", {}), ("big", 64, "lm", {}),         # lm<16,16,2> lm<32,8,2> lm<64,4,2>
@@ -1373,7 +1376,7 @@ def test_default_launches_of_the_fly_take_the_lean_kernels(fly_setup, monkeypatc
 
 @pytest.mark.parametrize("model,lanes,solver,env", _SHAPE_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else
                          "-".join(f"{k[9:]}{x}" for k, x in v.items()) or "auto")
-def test_every_shipped_instantiation_twice(rodent_setup, mouse_setup, rodent_mocap, monkeypatch, model, lanes, solver, env):
+def test_every_shipped_instantiation_twice(rodent_setup, mouse_setup, fly_setup, rodent_mocap, monkeypatch, model, lanes, solver, env):
     from oracle import Oracle
     from stac_mjx_amd.engine import Engine
 
@@ -1391,19 +1394,25 @@ def test_every_shipped_instantiation_twice(rodent_setup, mouse_setup, rodent_moc
         okw = dict(do_root_opt=True)
         tol = 1e-5
     else:
-        fs = rodent_setup if model == "rodent" else mouse_setup
+        fs = rodent_setup if model == "rodent" else (fly_setup if model == "fly" else mouse_setup)
         t, lb, ub, part, trunk, tol = fs.tables, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 1e-4
         orc = Oracle(t, tol=tol, maxiter=maxiter)
         if model == "rodent":
             kp = rodent_mocap[300:310].reshape(5, 2, 69)
             do_root = True
+        elif model == "fly":  # (tethered: no root optimisation)
+            rng = np.random.default_rng(78)
+            qm = t.qpos0[None] + np.clip(rng.normal(0, 0.15, (10, t.nq)), -0.3, 0.3).astype(np.float32)
+            qm[:, 3:7] = t.qpos0[3:7]
+            kp = np.stack([orc.fk(x)["site_xpos"].reshape(-1) for x in qm]).reshape(5, 2, 3 * t.nsite).astype(np.float32)
+            do_root = False
         else:
             rng = np.random.default_rng(77)
             qm = t.qpos0[None] + np.clip(rng.normal(0, 0.05, (6, t.nq)), -0.1, 0.1).astype(np.float32)
             qm[:, 3:7] = t.qpos0[3:7]
             kp = np.stack([orc.fk(x)["site_xpos"].reshape(-1) for x in qm]).reshape(3, 2, 3 * t.nsite).astype(np.float32)
             do_root = fs.do_root_opt
-        kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=fs.root_kp_idx, root_dims=fs.root_dims, do_root_opt=do_root)
+        kw = dict(part_masks=part, trunk_kps=trunk, root_kp_idx=max(fs.root_kp_idx, 0), root_dims=fs.root_dims, do_root_opt=do_root)
         okw = dict(do_root_opt=do_root)
     rk, rd = kw["root_kp_idx"], kw["root_dims"]
     if solver == "pg":
