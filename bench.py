@@ -63,6 +63,51 @@ def job_value(shape: dict, steps: int, elapsed_max_over_ranks: float) -> float:
     return shape["frames_total"] * steps / elapsed_max_over_ranks
 
 
+def rank_record(rank: int, shape: dict, kernel, kernel_ms: float, elapsed_s: float) -> dict:
+    """What one rank did in the timed region: its clips, the q_phase instantiation its LAST launch ran (<G, NQR, WPE, SPECP> from
+    stac_debug_last_q_kernel: a rank whose share falls into the latency regime runs another kernel than a full GPU does), the
+    mean HIP-event time of a step on its stream and its own wall time (the line's `value` only carries the slowest rank's)."""
+    return {"rank": int(rank), "clips": int(shape["clips_rank"]), "frames": int(shape["frames_rank"]),
+            "kernel": "q_phase_kernel<%d,%d,%d,%d>" % tuple(int(x) for x in kernel), "kernel_ms": float(kernel_ms),
+            "elapsed_s": float(elapsed_s)}
+
+
+def gather_rank_records(rec: dict, dist) -> list:
+    """Every rank's record on every rank, in rank order (one all_gather_object: control plane, after the timed region)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [rec]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, rec)
+    return sorted(out, key=lambda r: r["rank"])
+
+
+def predicted_value(model: str, shape: dict, world: int, table_path=None):
+    """The whole-job rate this line SHOULD show if every GPU ran its share at the committed single-GPU rate of that share
+    (profiles/single_gpu_rates.json: measured on one MI355X at the per-rank chain counts; log-linear between its rows).  The
+    slowest rank has the most clips (dist.shard_range: the first one).  None when the table has no rows for this kind of job."""
+    import math
+
+    try:
+        rows = [r for r in json.load(open(table_path or ROOT / "profiles" / "single_gpu_rates.json"))["rows"]
+                if r["model"] == model and r["frames_per_clip"] == shape["F"]]
+    except (FileNotFoundError, KeyError, ValueError):
+        return None
+    rows.sort(key=lambda r: r["chains"])
+    clips = -(-shape["clips_total"] // world)  # the largest share
+    if not rows or clips <= 0:
+        return None
+    if clips <= rows[0]["chains"]:
+        rate = rows[0]["frames_per_s"] * clips / rows[0]["chains"]  # below the table: a GPU this empty runs chains side by side
+    elif clips >= rows[-1]["chains"]:
+        rate = rows[-1]["frames_per_s"]
+    else:
+        hi = next(i for i, r in enumerate(rows) if r["chains"] >= clips)
+        a, b = rows[hi - 1], rows[hi]
+        w = (math.log(clips) - math.log(a["chains"])) / (math.log(b["chains"]) - math.log(a["chains"]))
+        rate = math.exp((1 - w) * math.log(a["frames_per_s"]) + w * math.log(b["frames_per_s"]))
+    return shape["frames_total"] / (clips * shape["F"] / rate)  # job frames over the slowest rank's predicted time
+
+
 def cpu_baseline(fs, cfg, kp_host, target_s=15.0):
     """The oracle (CPU restatement, kind='port') on a bounded sample of the same workload."""
     from oracle import Oracle
@@ -149,6 +194,9 @@ def run_fit_mode(args, rank, local_rank, world, dist):
             "parallelism": f"clips sharded over {world} GPU(s); offset phase: one all-reduce of {3 * fs.tables.nsite + 2} floats per "
                            f"calibration iteration ({n_pass - 1} per fit)",
             "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
+            # every rank's share and what it ran (a SCALE record can be diagnosed from the line alone), and the rate the committed
+            # single-GPU table predicts for this job (profiles/single_gpu_rates.json)
+            "per_rank": per_rank, "predicted_value": predicted_value(args.model, shape, world) if args.solver == "pg" else None,
             "mean_offset_error_mm_vs_generating_offsets": d_off,
         },
     }
@@ -352,6 +400,9 @@ def main():
     fs, cfg = load_setup(args.model)
     F = args.frames_per_clip
     strong = args.scaling == "strong"
+    if F < 1 or args.frames % F:
+        raise SystemExit(f"bench.py: --frames {args.frames} is not a multiple of --frames-per-clip {F} (the job would silently be "
+                         f"{args.frames // max(F, 1) * max(F, 1)} frames)")
     shape = job_shape(args.scaling, args.frames, F, rank, world)
     C_total, lo, hi, C = shape["clips_total"], shape["lo"], shape["hi"], shape["clips_rank"]
     eng = Engine(fs.tables, fs.lb, fs.ub, tol=float(cfg["FTOL"]), maxiter=int(cfg["N_ITER_Q"]), lanes_per_chain=args.lanes,
@@ -364,7 +415,7 @@ def main():
         # blocks its shard touches (uploaded block by block: 1 M frames are 276 MB of keypoints)
         kBlock = 500
         parts = []
-        for b in range(lo // kBlock, (max(hi, lo + 1) - 1) // kBlock + 1):
+        for b in (range(lo // kBlock, (hi - 1) // kBlock + 1) if hi > lo else ()):  # (a rank without clips -- more ranks than clips -- generates nothing)
             nb_ = min(kBlock, C_total - b * kBlock)
             blk, _ = synth_keypoints(fs, fk, nb_, F, seed=100 + 2 * b, noise_seed=101 + 2 * b)
             parts.append(torch.as_tensor(blk[max(lo - b * kBlock, 0):max(min(hi - b * kBlock, nb_), 0)]).to(eng.device))
@@ -378,6 +429,8 @@ def main():
 
     def step():
         nonlocal out
+        if C == 0:  # (a rank without clips still takes part in the barriers and the reductions)
+            return
         out = eng.q_phase(kp, part_masks=fs.part_masks, trunk_kps=fs.trunk_kps, root_kp_idx=fs.root_kp_idx,
                           root_dims=fs.root_dims, do_root_opt=fs.do_root_opt, want_bodies=False, want_markers=False, want_carry=False,
                           out=out)
@@ -397,19 +450,29 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed
     if dist:
         tmax = torch.tensor([elapsed], device=eng.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if C > 0 else 0.0
+    import ctypes
+
+    last_kernel = (ctypes.c_int32 * 4)()
+    eng.lib.stac_debug_last_q_kernel(last_kernel)
+    per_rank = gather_rank_records(rank_record(rank, shape, tuple(last_kernel), kern_ms, elapsed_rank), dist)
 
     frames_step = C * F  # this rank's frames per step
     value = job_value(shape, args.steps, elapsed)  # whole-job frames over the slowest rank's time
-    cnt = out["counters"].to(torch.float64).sum(dim=(0, 1)).cpu().numpy()
-    err = torch.linalg.norm((eng.fk(out["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
-                             - kp.reshape(-1, fs.tables.nsite, 3)), dim=-1)
+    if C > 0:
+        cnt = out["counters"].to(torch.float64).sum(dim=(0, 1)).cpu().numpy()
+        err = torch.linalg.norm((eng.fk(out["qpos"].reshape(-1, fs.tables.nq), want=("site_xpos",))["site_xpos"]
+                                 - kp.reshape(-1, fs.tables.nsite, 3)), dim=-1)
+    else:
+        cnt, err = np.zeros(4), torch.zeros(1, device=eng.device)
     # algorithmic bytes of the q_phase kernel: keypoints in, qpos + residual out (576 B/frame)
     bytes_frame = 12 * fs.tables.nsite + 4 * fs.tables.nq + 4
+    kern_ms = max(kern_ms, 1e-9)
     achieved = frames_step * bytes_frame / (kern_ms * 1e-3) / 1e9
     # algorithmic flops (full-tree constants): value+grad 17.9 kflop, loss 15.9 kflop
     flops = cnt[2] * 17.9e3 + cnt[1] * 15.9e3
@@ -440,8 +503,11 @@ def main():
             "frames_per_gpu": frames_step, "frames_total": C_total * F, "n_frames_per_clip": F, "lanes_per_chain": args.lanes or "auto",
             "parallelism": f"clips sharded over {world} GPU(s) (dist.shard_range: contiguous blocks), no data-path collective",
             "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
-            "iters_per_frame": cnt[0] / frames_step, "ls_evals_per_frame": cnt[1] / frames_step,
-            "grad_evals_per_frame": cnt[2] / frames_step,
+            # every rank's share and what it ran (a SCALE record can be diagnosed from the line alone), and the rate the committed
+            # single-GPU table predicts for this job (profiles/single_gpu_rates.json)
+            "per_rank": per_rank, "predicted_value": predicted_value(args.model, shape, world) if args.solver == "pg" else None,
+            "iters_per_frame": cnt[0] / max(frames_step, 1), "ls_evals_per_frame": cnt[1] / max(frames_step, 1),
+            "grad_evals_per_frame": cnt[2] / max(frames_step, 1),
             "marker_rmse_mm": float(torch.sqrt((err ** 2).mean()).item() * 1e3),
             "valu_tflops_algorithmic": flops / (kern_ms * 1e-3) / 1e12,
             "valu_frac_of_fp32_peak": flops / (kern_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
@@ -487,7 +553,8 @@ def main():
         from stac_mjx_amd.dist import offset_phase_exchange_probe
 
         n_s = min(frames_step, 100)
-        part = eng.m_partial(kp.reshape(-1, kp.shape[-1])[:n_s], out["qpos"].reshape(-1, fs.tables.nq)[:n_s])
+        q_s = out["qpos"].reshape(-1, fs.tables.nq)[:n_s] if C > 0 else torch.empty((0, fs.tables.nq), device=eng.device)
+        part = eng.m_partial(kp.reshape(-1, kp.shape[-1])[:n_s], q_s)  # (no frames on this rank: sums of zeros, T = 0)
         off_now = eng.get_site_pos()
         is_reg = torch.ones_like(off_now)
         probe = offset_phase_exchange_probe(part, lambda red: eng.m_finish(red, off_now, is_reg, 1.0)[0])
@@ -544,7 +611,7 @@ def main():
             "marker_rmse_mm": float(torch.sqrt((lerr ** 2).mean()).item() * 1e3),
             "lm_maxiter": args.lm_maxiter,
             "note": "stac_q_params.solver = STAC_SOLVER_LM; not the reference's algorithm, judged in marker space only"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.solver == "pg":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.solver == "pg" and C > 0:
         line["cpu_baseline"] = cpu_baseline(fs, cfg, kp_host)
     if rank == 0:
         print(json.dumps(line))

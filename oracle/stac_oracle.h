@@ -104,7 +104,9 @@ void orc_q_opt(const orc_model *m, const orc_pg_params *p, const float *kp,
  * Featherstone's L^T D L on the root paths (pivots in decreasing qpos order: no fill-in), y = L^-T b on the fly,
  * z = D^-1 y, d = L^-1 z ancestors first; step clipped to the box, accepted if the loss decreases (lambda /= 2) else
  * lambda *= 4 (at most 8 times in a row; a matrix that is not positive definite counts as a rejected evaluation of the
- * point itself).  Stops on the same residual as the PG solver (||clip(x - grad) - x|| <= tol) or after maxiter accepted
+ * point itself AND quadruples lambda once more on that turn: x 16 -- kernel and oracle alike, stac_lm.hip: the factorisation failed, so
+ * the damping is raised faster than after an ordinary rejected step; tests/test_gpu_parity.py keeps a check of the LM answer that does
+ * not go through this file: the marker-space comparison against the PG solver).  Stops on the same residual as the PG solver (||clip(x - grad) - x|| <= tol) or after maxiter accepted
  * steps.  A ball joint's four raw quaternion components are coordinates like the free root's (columns in the frame the ball
  * rotation is applied in, the same gauge term). */
 typedef struct {

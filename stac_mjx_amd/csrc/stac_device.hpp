@@ -87,6 +87,8 @@ __device__ __forceinline__ float xor_partner(float v) {
 }
 // Pairwise-tree sum over the elements e = r*G + lane_in_group of a striped vector (zeros beyond nq):
 // lane butterflies for the levels below G, then the registers.  Every lane of the group gets the sum.
+// (Round 6 tried gfx950's v_permlane16_swap / v_permlane32_swap for the two levels that cross a 16-lane row, instead of ds_swizzle /
+//  ds_bpermute: 3 % SLOWER on 250-frame clips, 13 % on the LM solver -- and not the xor-partner exchange this tree needs.  Dropped.)
 template <int G, int NQR>
 __device__ __forceinline__ float group_tree_sum(const float (&v)[NQR]) {
     constexpr int PR = NQR <= 1 ? 1 : NQR <= 2 ? 2 : NQR <= 4 ? 4 : NQR <= 8 ? 8 : NQR <= 16 ? 16 : 32;
@@ -1065,6 +1067,24 @@ __device__ __forceinline__ void fk3_p2(const float *T2, const int n2, float *CBc
             tk = tn; tn = tnn; q4 = qn;
         }
     }
+}
+// P2 of the lean latency kernels (round 6): the lane's tasks of the first NR rounds come out of registers (they never change: the
+// kernel reads them once), so a round is one LDS round trip -- its quaternion -- instead of two dependent ones; the NR quaternions are
+// requested together.  Rounds behind the NR-th run as before.
+template <int NR>
+__device__ __forceinline__ void fk3_p2_pinned(const float4 (&tk)[NR], const float *T2, const int n2, float *CBc, const int lf, const int gf) {
+    float4 q[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+        if (r * gf < n2) q[r] = lds4(CBc + (__builtin_bit_cast(int, tk[r].w) & 0xFFFF));  // (w, x, y, z)
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+        if (r * gf < n2) {
+            const V3 rt = rotate(V3{tk[r].x, tk[r].y, tk[r].z}, Q4{q[r].x, q[r].y, q[r].z, q[r].w});
+            float *o = CBc + (int)((unsigned)__builtin_bit_cast(int, tk[r].w) >> 16);
+            o[0] = rt.x; o[1] = rt.y; o[2] = rt.z;
+        }
+    if (NR * gf < n2) fk3_p2<false>(T2 + 4 * NR * gf, n2 - NR * gf, CBc, lf, gf);
 }
 // P3.  The slot of (step t, position pp) is pb + 3 * (4 t + pp).  Blocks of four steps, every block the same instructions: a position
 // either keeps its running value or starts the block from a restart value, T3[4 b + pp] = word of that value, or bit 31 | a valid word.

@@ -343,6 +343,82 @@ void q_phase_kernel(const QArgs a_in) {
         }
         sites1 = !SPEC && a.root_fast > 0 && !__any(cnt > 1);
     }
+    // ---- lean latency kernels: what a lane reads from the plan in EVERY trip, kept in registers (round 6) ---------------------------
+    // A lone wavefront waits out every LDS round trip, and the per-item phases of a trip begin with two or three DEPENDENT ones: the item's
+    // record (which joint / site / rotation is this lane's?), then the addresses in it, then the data.  The lane's items never change, and
+    // these kernels have a hundred vector registers to spare: the records of the lane's sites and of its joints of the pre-pass are read
+    // once, here (the full program's; a root pass -- the first frame of a clip only -- reads the pruned program's site words as before).
+#ifndef STAC_NO_LATPIN
+    constexpr bool LATPIN = LEAN && SPEC != 0 && NQR <= 5;  // (the wide shapes -- eight solver registers per lane -- have no registers to spare)
+#else
+    constexpr bool LATPIN = false;
+#endif
+    constexpr int PJ = LATPIN ? (G == 32 ? 2 : 3) : 1;  // rounds of the pre-pass whose joints are pinned (rodent: all of them)
+    float4 pin_sr[NSR];      // SiteRec of the lane's sites
+    int pin_s3[NSR];         // their body position / quaternion words under the full program
+    int pin_jad[PJ], pin_jout[PJ];
+    float pin_jq0[PJ], pin_jax[PJ][3];
+    if constexpr (LATPIN) {
+        const int *site3f = reinterpret_cast<const int *>(P + H.off3_prog) + 16 * (H.fk3_cap1 + 2) + 4 * H.fk3_cap2 + 4 * H.fk3_cap3;
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) {
+            const int k = min(r * G + lg, K - 1);
+            pin_sr[r] = lds4(srec + 4 * k);
+            pin_s3[r] = site3f[k];
+            asm volatile("" : "+v"(pin_sr[r].x), "+v"(pin_sr[r].y), "+v"(pin_sr[r].z), "+v"(pin_sr[r].w), "+v"(pin_s3[r]));
+        }
+#pragma unroll
+        for (int u = 0; u < PJ; ++u) {
+            const int j = min(lg + 1 + u * G, H.naj - 1);  // (a lane without a joint in this round repeats the last one: the same value to the same words)
+            const float *jr = jrec + 12 * j;
+            pin_jad[u] = reinterpret_cast<const int *>(jr)[1];
+            pin_jq0[u] = jr[7];
+            pin_jax[u][0] = jr[8]; pin_jax[u][1] = jr[9]; pin_jax[u][2] = jr[10];
+            pin_jout[u] = H.c3_ql + 4 * j;
+            asm volatile("" : "+v"(pin_jad[u]), "+v"(pin_jq0[u]), "+v"(pin_jax[u][0]), "+v"(pin_jax[u][1]), "+v"(pin_jax[u][2]), "+v"(pin_jout[u]));
+        }
+    }
+    // ... the rotations of the lane's first PR2 rounds of P2 (full program), the joint of the gradient pass's first round and the range
+    // tasks of its first two (the lanes of a chain's wavefronts take joint `lane` / task `lane`, `lane + 64`)
+    constexpr int PR2 = 3;
+    float4 pin_t2[LATPIN ? PR2 : 1];
+    struct GPin { int ad, rw, jw, j; float ax, ay, az; };  // qpos address, word of the range sum, anchor / pre-joint quaternion words, joint
+    struct TPin { int lo, hi, src, dst; };                  // site range, word of the first site's component, word of the sum
+    GPin pin_g = {};
+    TPin pin_t[LATPIN ? 3 : 1] = {};
+    if constexpr (LATPIN) {
+        const float *T2f = P + H.off3_prog + 16 * (H.fk3_cap1 + 2);
+        const int n2f = (int)((unsigned)H.fk3_n >> 16);
+#pragma unroll
+        for (int r = 0; r < PR2; ++r) {
+            pin_t2[r] = lds4(T2f + 4 * min(r * G + lg, n2f - 1));
+            asm volatile("" : "+v"(pin_t2[r].x), "+v"(pin_t2[r].y), "+v"(pin_t2[r].z), "+v"(pin_t2[r].w));
+        }
+        constexpr int LCp = (G * NR >= 64) ? 64 : G * NR;
+        {   // the joint this lane takes in the first round of the gradient pass: `lane` of the chain's lanes (NW == 1: the two evaluations' joints one after the other)
+            const int ll = lane % LCp;
+            const int j = NW > 1 ? min(ll, H.naj - 1) : (ll >= H.naj ? min(ll - H.naj, H.naj - 1) : ll);
+            const float *jr = jrec + 12 * j;
+            pin_g.j = j;
+            pin_g.ad = reinterpret_cast<const int *>(jr)[1];
+            pin_g.ax = jr[8]; pin_g.ay = jr[9]; pin_g.az = jr[10];
+            pin_g.rw = H.c_rw + kXf * reinterpret_cast<const int *>(jr)[11];
+            pin_g.jw = reinterpret_cast<const int *>(P + H.off3_site)[K + j];
+            asm volatile("" : "+v"(pin_g.ad), "+v"(pin_g.rw), "+v"(pin_g.jw), "+v"(pin_g.j), "+v"(pin_g.ax), "+v"(pin_g.ay), "+v"(pin_g.az));
+        }
+        if constexpr (NW > 1) {  // range tasks: [0], [1] = the owner's first two (t = base + lane, + 64), [2] = the helper's (component `lane` of range 0)
+            const RangeRec *rrec_p = reinterpret_cast<const RangeRec *>(P + H.off_range);
+            const int base = NW == 2 ? 0 : 6;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int t = u < 2 ? min(base + lane + 64 * u, 6 * H.nrange - 1) : min(lane, 5);
+                const int r = t / 6, k = t - 6 * r;
+                const int co = k < 3 ? k : kXq + k - 3;
+                pin_t[u] = TPin{rrec_p[r].lo, rrec_p[r].hi, H.c_sw + co, H.c_rw + kXf * r + co};
+                asm volatile("" : "+v"(pin_t[u].lo), "+v"(pin_t[u].hi), "+v"(pin_t[u].src), "+v"(pin_t[u].dst));
+            }
+        }
+    }
     PROF_DECL;
     // ================================= main loop: one q_loss evaluation per trip ==================
     const int lg_outer = lg;
@@ -627,7 +703,17 @@ void q_phase_kernel(const QArgs a_in) {
                 // joint again: the same value to the same words.
                 // (throughput kernels: a lone wavefront of the latency kernels pays per instruction, dependent or not)
                 constexpr int U = SPEC != 0 ? (G == 32 ? 2 : 1) : (G == 16 ? 3 : 2);
-                for (int j0 = lg + 1; j0 < H.naj; j0 += U * G) {
+                if constexpr (LATPIN) {  // (the lane's joints of the first PJ rounds out of registers: LATPIN, above)
+#pragma unroll
+                    for (int u = 0; u < PJ; ++u) {
+                        if (u > 0 && 1 + u * G >= H.naj) break;  // (wave-uniform: no joint left for any lane)
+                        const float angle = qe[pin_jad[u]] - pin_jq0[u];
+                        float sn, cs;
+                        sincos_(angle * 0.5f, &sn, &cs);
+                        *reinterpret_cast<float4 *>(CB + pin_jout[u]) = float4{cs, pin_jax[u][0] * sn, pin_jax[u][1] * sn, pin_jax[u][2] * sn};
+                    }
+                }
+                for (int j0 = lg + 1 + (LATPIN ? PJ * G : 0); j0 < H.naj; j0 += U * G) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int j = min(j0 + u * G, H.naj - 1);
@@ -677,7 +763,18 @@ void q_phase_kernel(const QArgs a_in) {
                 PROF_TICK(9);
             }
 #else
-            fk3_run<(SPEC == 0 && G == 16)>(G3, CB, H.c3_pb, lg, G);
+            if constexpr (LATPIN) {
+                const Fk3Lane L3 = fk3_lane(lg & 15);
+                if (G == 16 || lg < 16) fk3_p1(G3.T1, G3.n1 >> 1, CB, L3);
+                wave_sync();
+                if (rootp) fk3_p2<false>(G3.T2, G3.n2, CB, lg, G);  // (a root pass runs the pruned program's rotations)
+                else fk3_p2_pinned<PR2>(pin_t2, G3.T2, G3.n2, CB, lg, G);
+                wave_sync();
+                if (G == 16 || lg < 16) fk3_p3(G3.T3, G3.n3 >> 2, CB, H.c3_pb, L3);
+                wave_sync();
+            } else {
+                fk3_run<(SPEC == 0 && G == 16)>(G3, CB, H.c3_pb, lg, G);
+            }
 #endif
         } else {
             fk_chain<(G >= 16), (G == 16 && !SPEC)>(H, P, CB, lg, G, true, any_grad, (a.flags & 2) != 0, n_ml_root, a.n_run_root);
@@ -693,13 +790,21 @@ void q_phase_kernel(const QArgs a_in) {
         const int Kpad = (K + 3) & ~3;
         // one site: world position, weighted residual against the keypoint (kx, ky, kz), loss term; the wrench
         // (f, (x - c) x f) goes to its place in DFS-site order
-        auto site_term = [&](const int k, const float kx, const float ky, const float kz, const bool tw) -> float {
-            const float4 sr = lds4(srec + 4 * k);
+        auto site_term = [&](const int k, const float kx, const float ky, const float kz, const bool tw, const int rr = -1) -> float {
+            float4 sr;
+            if constexpr (LATPIN) sr = pin_sr[rr < 0 ? 0 : rr];  // (the latency kernels call it with the round: site_regs)
+            else sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
             V3 bpos_w;
             Q4 bquat_w;
             if constexpr (LEAN) {
-                const int s3 = site3[k];
+                int s3;
+                if constexpr (LATPIN) {
+                    s3 = pin_s3[rr < 0 ? 0 : rr];
+                    if (n_ml_root > 0) s3 = site3[k];  // (wave-uniform: a root pass ran the pruned program)
+                } else {
+                    s3 = site3[k];
+                }
                 bpos_w = ld3(CB + (s3 & 0xFFFF));
                 const float4 q4 = lds4(CB + (int)((unsigned)s3 >> 16));
                 bquat_w = Q4{q4.x, q4.y, q4.z, q4.w};
@@ -749,7 +854,7 @@ void q_phase_kernel(const QArgs a_in) {
 #pragma unroll
             for (int r = 0; r < NSR; ++r) {
                 const int k = r * G + lg;
-                term[r] = k < K ? site_term(k, kpr[r][0], kpr[r][1], kpr[r][2], ((kpw_bits >> r) & 1u) != 0) : 0.0f;
+                term[r] = k < K ? site_term(k, kpr[r][0], kpr[r][1], kpr[r][2], ((kpw_bits >> r) & 1u) != 0, r) : 0.0f;
             }
             }
             loss = group_tree_sum<G, NSR>(term);
@@ -841,6 +946,21 @@ void q_phase_kernel(const QArgs a_in) {
         // site instead of four reads and six adds, and the six tasks of a range sit on neighbouring lanes (equal trip
         // counts; the ranges are sorted longest first).  The longest range -- every site, for the root's joint -- sets
         // the length of this phase.  (With 16 lanes the extra rounds cost more than they save: measured -8 %.)
+        // (the same task out of registers -- latency kernels, the lane's first tasks: LATPIN)
+        auto range_task_pinned = [&](const auto &tp, float *CBx) {
+            const float *src = CBx + tp.src;
+            float acc = 0.f;
+            const int last = tp.hi - 1;
+            constexpr int RT = STAC_RT;
+            for (int i = tp.lo; i < tp.hi; i += RT) {
+                float v[RT];
+#pragma unroll
+                for (int u = 0; u < RT; ++u) v[u] = src[kXf * min(i + u, last)];
+#pragma unroll
+                for (int u = 0; u < RT; ++u) acc = i + u <= last ? acc + v[u] : acc;
+            }
+            CBx[tp.dst] = acc;
+        };
         auto range_task = [&](const int t, float *CBx) {
             const int r = t / 6, k = t - 6 * r;
             const RangeRec rr = rrec[r];
@@ -879,18 +999,27 @@ void q_phase_kernel(const QArgs a_in) {
         // (lean kernels: the joints this is called for -- all but the free root, which has its own path -- are hinges: the host has
         //  checked that the model has no ball joint and that its FK program is uniform, launch_q_phase)
         constexpr bool LEAN_HINGES = LEAN && SPEC == 0;  // (the latency kernels pass the free root through here as well)
-        auto joint_gradient = [&](const int j, float *CBx, const V3 crefx, float *ggx) {
+        auto joint_gradient = [&](const int j, float *CBx, const V3 crefx, float *ggx, const bool pinned = false) {
             const float *jax_ = CBx + H.c_ja, *qsvx = CBx + H.c_qsv, *jnx = CBx + H.c_jn;
             const float *jr = jrec + 12 * j;
-            const int4 ji = lds4i(jr);  // type, qadr, slo, shi
-            const int ty = ji.x, ad = ji.y;
-            const float4 ja4 = lds4(jr + 8);  // axis, range id
-            const float *rw = CBx + H.c_rw + kXf * __builtin_bit_cast(int, ja4.w);
+            int ty = JHINGE, ad;
+            float4 ja4;
+            const float *rw;
+            if (LATPIN && pinned) {  // (the lane's joint of the first round: its record out of registers)
+                ad = pin_g.ad;
+                ja4 = float4{pin_g.ax, pin_g.ay, pin_g.az, 0.0f};
+                rw = CBx + pin_g.rw;
+            } else {
+                const int4 ji = lds4i(jr);  // type, qadr, slo, shi
+                ty = ji.x; ad = ji.y;
+                ja4 = lds4(jr + 8);  // axis, range id
+                rw = CBx + H.c_rw + kXf * __builtin_bit_cast(int, ja4.w);
+            }
             const V3 Fs = ld_tpos(rw), T0 = ld_tvec2(rw);
                 V3 anchor;
                 Q4 prequat;
                 if constexpr (LEAN) {  // (split kinematics: where the joint's anchor and its pre-joint quaternion are, from the full program's joint words)
-                    const int jw = reinterpret_cast<const int *>(P + H.off3_site)[K + j];
+                    const int jw = (LATPIN && pinned) ? pin_g.jw : reinterpret_cast<const int *>(P + H.off3_site)[K + j];
                     anchor = ld3(CBx + (jw & 0xFFFF));
                     const float4 q4 = lds4(CBx + (int)((unsigned)jw >> 16));
                     prequat = Q4{q4.x, q4.y, q4.z, q4.w};
@@ -1241,7 +1370,13 @@ void q_phase_kernel(const QArgs a_in) {
                         range_sum(H.rsplit + (nx ? i - nw : i), nx ? CBn : CBa);
                     }
                     wave_sync();
-                    for (int i = ll; i < 2 * H.naj; i += LC) {
+                    if constexpr (LATPIN) {
+                        if (ll < 2 * H.naj) {  // first round: the lane's joint out of registers
+                            const bool nx = ll >= H.naj;
+                            joint_gradient(pin_g.j, nx ? CBn : CBa, nx ? crefn : crefa, nx ? gxn : gxa, true);
+                        }
+                    }
+                    for (int i = ll + (LATPIN ? LC : 0); i < 2 * H.naj; i += LC) {
                         const bool nx = i >= H.naj;
                         joint_gradient(nx ? i - H.naj : i, nx ? CBn : CBa, nx ? crefn : crefa, nx ? gxn : gxa);
                     }
@@ -1259,13 +1394,28 @@ void q_phase_kernel(const QArgs a_in) {
                         const bool first = mine ? wa == wave : wa == (wave ^ 1);
                         float *gx = first ? gxa : gxn, *CBx = first ? CBa : CBn;
                         const V3 crefx = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_bx + kXf);
+                        if constexpr (LATPIN) {  // (the lane's first two tasks / the helper's one out of registers)
+                            const int base = SOLO ? 0 : 6;
+                            if (mine) {
+                                if (base + lane < 6 * H.nrange) range_task_pinned(pin_t[0], CBx);
+                                if (base + lane + 64 < 6 * H.nrange) range_task_pinned(pin_t[1], CBx);
+                                for (int t = base + lane + 128; t < 6 * H.nrange; t += 64) range_task(t, CBx);
+                            } else if (lane < 6) range_task_pinned(pin_t[2], CBx);
+                        } else {
                         if (mine) { for (int t = (SOLO ? 0 : 6) + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
                         else if (lane < 6) range_task(lane, CBx);
+                        }
                         wave_sync();
 #if defined(STAC_PROFILE) && defined(STAC_PROF_GRAD)  // (diagnostic: the range sums of the latency kernels' gradient pass charged to stamp 9)
                         PROF_TICK(9);
 #endif
-                        for (int j = lane; j < H.naj; j += 64) {
+                        if constexpr (LATPIN) {
+                            if (lane < H.naj) {  // first round: the lane's joint out of registers
+                                const bool on_longest = pin_g.rw == H.c_rw;  // (range 0)
+                                if (SOLO || on_longest != mine) joint_gradient(pin_g.j, CBx, crefx, gx, true);
+                            }
+                        }
+                        for (int j = lane + (LATPIN ? 64 : 0); j < H.naj; j += 64) {
                             const bool on_longest = __builtin_bit_cast(int, jrec[12 * j + 11]) == 0;
                             if (SOLO || on_longest != mine) joint_gradient(j, CBx, crefx, gx);
                         }

@@ -133,11 +133,12 @@ def resolve_output_path(file_path) -> Path:
 # `io.py:224-236` fixes the container and the filter (h5py datasets with compression="gzip"), not how the deflate streams are
 # produced.  h5py deflates chunk after chunk on ONE thread: 5.4 s for the 273 MB of a 100 000-frame rodent run, seven times the
 # GPU time of the run itself.  Here the chunks are deflated by a thread pool (zlib releases the GIL) and handed
-# to HDF5 ready-made (`write_direct_chunk`: same filter pipeline, same chunk layout as an h5py write would leave, any reader
-# inflates them); the `.npz` stand-in of an interpreter without h5py gets the same treatment (its members are ordinary
+# to HDF5 ready-made (`write_direct_chunk`: the same filter pipeline as an h5py write -- any reader inflates them --; the chunks are
+# row blocks of about 1 MiB, not h5py's auto-chunk guess, which readers do not see; at most a window of compressed chunks is in memory
+# at a time, and the ranks of a node divide its cores among themselves); the `.npz` stand-in of an interpreter without h5py gets the same treatment (its members are ordinary
 # deflate streams put together pigz-style from independently compressed blocks).
 _PAR_MIN_BYTES = 1 << 20   # arrays below this are written the plain way
-_NPZ_BLOCK = 4 << 20       # bytes of input per deflate block of an .npz member
+_NPZ_BLOCK = 1 << 20       # bytes of input per deflate block of an .npz member (a block is 40 ms of one core at level 6)
 _H5_GZIP_LEVEL = 4         # h5py's default for compression="gzip" (the reference passes no level)
 
 
@@ -148,7 +149,28 @@ def _n_threads() -> int:
         n = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         n = os.cpu_count() or 1
-    return max(1, min(n, 64))
+    # one process per GPU: the ranks of a node share its cores (per-rank shard files are written by every rank at once)
+    try:
+        local_world = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
+    except ValueError:
+        local_world = 1
+    return max(1, min(n // local_world, 128))
+
+
+def _map_window(pool, fn, jobs, window=None):
+    """``pool.map`` in order with a bounded number of jobs in flight (results are consumed -- written -- as they come, so at most
+    ``window`` compressed chunks exist at a time instead of the whole dataset's)."""
+    from collections import deque
+
+    window = window or 4 * _n_threads()
+    pending = deque()
+    it = iter(jobs)
+    for job in it:
+        pending.append(pool.submit(fn, job))
+        if len(pending) >= window:
+            yield pending.popleft().result()
+    while pending:
+        yield pending.popleft().result()
 
 
 def _pool():
@@ -177,7 +199,7 @@ def _h5_write_parallel(f, name, arr, pool):
         return zlib.compress(memoryview(blk).cast("B"), _H5_GZIP_LEVEL)
 
     zeros = (0,) * (arr.ndim - 1)
-    for i, comp in enumerate(pool.map(deflate, range(n_chunks))):  # (in order; HDF5 itself is single-threaded)
+    for i, comp in enumerate(_map_window(pool, deflate, range(n_chunks))):  # (in order; HDF5 itself is single-threaded)
         d.id.write_direct_chunk((i * rows,) + zeros, comp)
 
 
@@ -189,46 +211,98 @@ def _npy_bytes_header(arr) -> bytes:
     return b.getvalue()
 
 
+def _crc32_combine(crc1: int, crc2: int, len2: int) -> int:
+    """CRC-32 of A + B from crc32(A), crc32(B) and len(B): appending len2 zero bytes to A is a linear map of the CRC register over
+    GF(2) (a 32 x 32 bit matrix, squared log2(len2) times), then the two CRCs add.  Lets every deflate block carry its own CRC."""
+    if len2 <= 0:
+        return crc1
+
+    def times(mat, vec):
+        out, i = 0, 0
+        while vec:
+            if vec & 1:
+                out ^= mat[i]
+            vec >>= 1
+            i += 1
+        return out
+
+    def square(mat):
+        return [times(mat, mat[i]) for i in range(32)]
+
+    odd = [0xEDB88320] + [1 << (i - 1) for i in range(1, 32)]  # one zero BIT appended (reflected polynomial)
+    even = square(odd)   # two bits
+    odd = square(even)   # four bits
+    n = len2
+    while True:  # (first pass: eight bits = one zero byte per unit of n)
+        even = square(odd)
+        if n & 1:
+            crc1 = times(even, crc1)
+        n >>= 1
+        if not n:
+            break
+        odd = square(even)
+        if n & 1:
+            crc1 = times(odd, crc1)
+        n >>= 1
+        if not n:
+            break
+    return (crc1 ^ crc2) & 0xFFFFFFFF
+
+
 def _npz_write_parallel(path, members: dict, pool, level: int = 6) -> None:
     """``np.savez_compressed`` with the deflate work spread over the pool: every member is a plain ZIP_DEFLATED entry whose
     stream is the concatenation of independently compressed blocks (each ended with a sync flush, the last one finished), so
-    ``np.load`` / ``zipfile`` read it like any other .npz.  ZIP64 throughout (members can exceed 4 GiB)."""
+    ``np.load`` / ``zipfile`` read it like any other .npz.  ZIP64 throughout (members can exceed 4 GiB).  The blocks of ALL members
+    form one job stream (no member waits for the tail of the one before it), each block carries its own CRC (combined per
+    member: _crc32_combine), and at most a window of compressed blocks is in memory at a time."""
     import struct
     import zlib
 
-    def deflate(args):
-        buf, last = args
+    def deflate(job):
+        buf, last = job
         c = zlib.compressobj(level, zlib.DEFLATED, -15)
-        return c.compress(buf) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
+        return c.compress(buf) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(buf), len(buf)
 
+    plan, jobs = [], []  # per member: (file name, blocks); the job stream over all of them
+    for name, arr in members.items():
+        arr = np.asarray(arr)
+        if arr.dtype.hasobject:
+            raise ValueError("object arrays are not written")
+        arr = np.ascontiguousarray(arr)
+        raw = memoryview(arr.reshape(-1)).cast("B") if arr.size else memoryview(b"")
+        head = _npy_bytes_header(arr)
+        blocks = [bytes(head) + bytes(raw[:max(_NPZ_BLOCK - len(head), 0)])]
+        pos = max(_NPZ_BLOCK - len(head), 0)
+        while pos < len(raw):
+            blocks.append(raw[pos:pos + _NPZ_BLOCK])
+            pos += _NPZ_BLOCK
+        plan.append(((name + ".npy").encode(), len(blocks)))
+        jobs.extend((b, i == len(blocks) - 1) for i, b in enumerate(blocks))
+    results = _map_window(pool, deflate, jobs)
     central = []
     with open(path, "wb") as fh:
-        for name, arr in members.items():
-            arr = np.asarray(arr)
-            if arr.dtype.hasobject:
-                raise ValueError("object arrays are not written")
-            arr = np.ascontiguousarray(arr)
-            raw = memoryview(arr.reshape(-1)).cast("B") if arr.size else memoryview(b"")
-            head = _npy_bytes_header(arr)
-            blocks = [bytes(head) + bytes(raw[:max(_NPZ_BLOCK - len(head), 0)])]
-            pos = max(_NPZ_BLOCK - len(head), 0)
-            while pos < len(raw):
-                blocks.append(raw[pos:pos + _NPZ_BLOCK])
-                pos += _NPZ_BLOCK
-            jobs = [(b, i == len(blocks) - 1) for i, b in enumerate(blocks)]
-            crc_f = pool.submit(lambda bl=blocks: __import__("functools").reduce(lambda c, b: zlib.crc32(b, c), bl, 0))
-            comp = list(pool.map(deflate, jobs))
-            crc = crc_f.result() & 0xFFFFFFFF
-            csize, usize = sum(map(len, comp)), sum(len(b) for b in blocks)
-            fname = (name + ".npy").encode()
+        for fname, n_blocks in plan:
             offset = fh.tell()
-            extra = struct.pack("<HHQQ", 1, 16, usize, csize)
-            # local header: version 45 (ZIP64), no flags, deflate, DOS time 1980-01-01
-            fh.write(struct.pack("<IHHHHHIIIHH", 0x04034B50, 45, 0, 8, 0, 0x21, crc, 0xFFFFFFFF, 0xFFFFFFFF, len(fname), len(extra)))
+            # local header: version 45 (ZIP64), no flags, deflate, DOS time 1980-01-01; CRC and sizes are patched in once the member's
+            # blocks have been written
+            fh.write(struct.pack("<IHHHHHIIIHH", 0x04034B50, 45, 0, 8, 0, 0x21, 0, 0xFFFFFFFF, 0xFFFFFFFF, len(fname), 20))
             fh.write(fname)
-            fh.write(extra)
-            for c in comp:
-                fh.write(c)
+            extra_at = fh.tell()
+            fh.write(struct.pack("<HHQQ", 1, 16, 0, 0))
+            crc = csize = usize = 0
+            for _ in range(n_blocks):
+                comp, bcrc, blen = next(results)
+                fh.write(comp)
+                crc = _crc32_combine(crc, bcrc, blen) if usize else bcrc
+                csize += len(comp)
+                usize += blen
+            crc &= 0xFFFFFFFF
+            end = fh.tell()
+            fh.seek(offset + 14)
+            fh.write(struct.pack("<I", crc))
+            fh.seek(extra_at)
+            fh.write(struct.pack("<HHQQ", 1, 16, usize, csize))
+            fh.seek(end)
             central.append((fname, crc, csize, usize, offset))
         cd_start = fh.tell()
         for fname, crc, csize, usize, offset in central:

@@ -249,6 +249,12 @@ def _bench_shape_worker(rank, world, port, q):
             t = torch.tensor([1.0 + rank])
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
             out[name] = dict(sh, value=bench.job_value(sh, 3, float(t.item())))
+            # round 6: what each rank did travels in the line (config.per_rank), next to the rate the committed single-GPU table predicts
+            rec = bench.rank_record(rank, sh, (16, 5, 3, 1) if rank == 0 else (32, 3, 2, 9), 10.0 + rank, 1.0 + rank)
+            out[name]["per_rank"] = bench.gather_rank_records(rec, tdist)
+            out[name]["predicted"] = bench.predicted_value("rodent", sh, world)
+        one = bench.job_shape("strong", 250, 250, rank, world)  # more ranks than clips: the last rank owns nothing
+        out["one_clip"] = dict(one, per_rank=bench.gather_rank_records(bench.rank_record(rank, one, (32, 3, 2, 9), 0.0, 0.5), tdist))
         q.put((rank, out, None))
     except Exception as exc:  # noqa: BLE001
         q.put((rank, None, repr(exc)))
@@ -257,6 +263,8 @@ def _bench_shape_worker(rank, world, port, q):
 
 
 def test_bench_strong_and_weak_frame_accounting_two_ranks():
+    import bench
+
     """bench.py's sharding arithmetic under a live world-size-2 group (ADVICE r4: the run-mode line counted frames N times;
     VERDICT r4 #4: a strong-scaling mode on BASELINE configs[3]): the ranks' blocks tile the clips, `frames_total` is the
     job's, `value` = frames_total x steps / the slowest rank's time and is identical on every rank."""
@@ -282,6 +290,28 @@ def test_bench_strong_and_weak_frame_accounting_two_ranks():
     assert res[0]["odd"]["clips_rank"] == 501 and res[1]["odd"]["clips_rank"] == 500  # earlier ranks take the remainder
     assert res[0]["weak"]["frames_total"] == 20_000 and res[0]["weak"]["frames_rank"] == res[1]["weak"]["frames_rank"] == 10_000
     assert res[0]["run"]["frames_total"] == 200_000 and res[1]["run"]["clips_rank"] == 400
+    # per-rank records: the same list on every rank, in rank order, each rank's own clips / kernel / times
+    for name in ("cfg3", "odd", "weak", "run"):
+        pr = res[0][name]["per_rank"]
+        assert pr == res[1][name]["per_rank"] and [r["rank"] for r in pr] == [0, 1]
+        assert [r["clips"] for r in pr] == [res[0][name]["clips_rank"], res[1][name]["clips_rank"]]
+        assert pr[0]["kernel"] == "q_phase_kernel<16,5,3,1>" and pr[1]["kernel"] == "q_phase_kernel<32,3,2,9>"
+        assert [r["kernel_ms"] for r in pr] == [10.0, 11.0] and [r["elapsed_s"] for r in pr] == [1.0, 2.0]
+    assert [r["clips"] for r in res[0]["one_clip"]["per_rank"]] == [1, 0]
+    # predicted rate: two ranks of 2 000 clips each run at the table's 2 000-chain rate -> twice that; the weak default twice the
+    # 10 000-chain rate; a job whose shape the table does not hold has no prediction
+    import json
+
+    rows = {(r["frames_per_clip"], r["chains"]): r["frames_per_s"] for r in json.load(open(ROOT / "profiles" / "single_gpu_rates.json"))["rows"]
+            if r["model"] == "rodent"}
+    assert res[0]["cfg3"]["predicted"] == res[1]["cfg3"]["predicted"] == pytest.approx(2 * rows[(250, 2000)])
+    assert res[0]["weak"]["predicted"] == pytest.approx(2 * rows[(1, 10000)])
+    lo_, hi_ = rows[(250, 500)], rows[(250, 1000)]
+    assert 2 * lo_ * 400 / 500 < res[0]["run"]["predicted"] * 1.0001 and res[0]["run"]["predicted"] <= 2 * lo_  # 400 clips per rank: below the 500-chain row
+    assert 501 * 250 / (res[0]["odd"]["predicted"] and 1001 * 250 / res[0]["odd"]["predicted"]) == pytest.approx(
+        np.exp(np.interp(np.log(501), np.log([500, 1000]), np.log([lo_, hi_]))), rel=1e-6)
+    assert bench.predicted_value("rodent", dict(res[0]["cfg3"], F=7), 2) is None
     # the JSON line carries the mode it ran in
     src = (ROOT / "bench.py").read_text()
+    assert '"per_rank": per_rank' in src and '"predicted_value"' in src
     assert '"scaling": args.scaling' in src and "BASELINE configs[3]" in src

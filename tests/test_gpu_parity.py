@@ -605,7 +605,7 @@ TOL_LM_MARKERS = 0.0    # since round 5 oracle/stac_oracle.c::q_opt_lm_ws is the
 
 
 @pytest.mark.parametrize("lanes", [16, 32, 64])
-def test_lm_q_phase_matches_oracle_lm_in_marker_space(rodent_setup, rodent_mocap, lanes):
+def test_lm_q_phase_equals_oracle_lm_bit_for_bit(rodent_setup, rodent_mocap, lanes):
     """The optional LM solver against its CPU statement: the same evaluations, Gauss-Newton entries, L^T D L pivots, steps and
     accept / reject turns -- qpos, stopping residuals and counters bit for bit (until round 4 the oracle ran a dense Cholesky and
     the two were compared in marker space at 0.5 mm)."""
