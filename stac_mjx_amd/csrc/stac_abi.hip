@@ -1024,7 +1024,9 @@ static int spec_xch_words(const PlanHeader &h) { return 64 + 4 * h.nqpad + 4; }
 // nr = evaluation roles per chain: 8, or 4 (two chains per wavefront at 8 lanes per role: large batches)
 static size_t spec_lds_bytes(const PlanHeader &h, int G, int nkinds, int chains, int nr = 8) {
     const int plan_words = (h.total_words - h.plan_skip + 3) & ~3;
-    return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (nr * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float);
+    // (+ 1 KB: the range sums of the latency kernels read up to 23 site entries behind a range's end -- unclamped addresses, the values
+    //  dropped --, which behind the workgroup's last chain would leave the allocation)
+    return (size_t)(plan_words + q_mb_words(nkinds, G) + chains * (nr * q_chain_stride(h, G) + spec_xch_words(h))) * sizeof(float) + 1024;
 }
 struct SpecShape { int G, chains_per_block, waves_per_block; long resident; };  // resident = chains the chip holds at once
 // The one-wavefront-per-chain latency kernel (kLatG lanes per role: straggler hand-off, large clip counts) exists up to 8

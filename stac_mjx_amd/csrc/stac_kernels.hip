@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "stac_plan.hpp"
 #include "stac_device.hpp"
@@ -946,20 +947,32 @@ void q_phase_kernel(const QArgs a_in) {
         // site instead of four reads and six adds, and the six tasks of a range sit on neighbouring lanes (equal trip
         // counts; the ranges are sorted longest first).  The longest range -- every site, for the root's joint -- sets
         // the length of this phase.  (With 16 lanes the extra rounds cost more than they save: measured -8 %.)
-        // (the same task out of registers -- latency kernels, the lane's first tasks: LATPIN)
-        auto range_task_pinned = [&](const auto &tp, float *CBx) {
-            const float *src = CBx + tp.src;
+        // One component of a range's sum in the latency kernels: the n values from p0 on (a site every kXf words), left to right from zero,
+        // RT values per trip.  The values behind the range's end are READ (one address register and immediate offsets instead of a
+        // clamped index per value: the words behind a chain's last site are the chain's own slack, the next chain's region or the slack
+        // behind the workgroup's last chain -- spec_lds_bytes) and their additions dropped: the same sum.
+        auto range_acc = [&](auto rt_c, const float *p0, const int n) -> float {
+            constexpr int RT = decltype(rt_c)::value;
             float acc = 0.f;
-            const int last = tp.hi - 1;
-            constexpr int RT = STAC_RT;
-            for (int i = tp.lo; i < tp.hi; i += RT) {
+            const float *p = p0;
+            for (int m = n; m > 0; m -= RT, p += kXf * RT) {  // (m: values left -- one compare against a constant per value)
                 float v[RT];
 #pragma unroll
-                for (int u = 0; u < RT; ++u) v[u] = src[kXf * min(i + u, last)];
+                for (int u = 0; u < RT; ++u) v[u] = p[kXf * u];
 #pragma unroll
-                for (int u = 0; u < RT; ++u) acc = i + u <= last ? acc + v[u] : acc;
+                for (int u = 0; u < RT; ++u) acc = u < m ? acc + v[u] : acc;
             }
-            CBx[tp.dst] = acc;
+            return acc;
+        };
+        // by the longest range of the round (wave-uniform): four, twelve or twenty-four values per trip
+        auto range_acc_by = [&](const int maxn, const float *p0, const int n) -> float {
+            if (maxn <= 4) return range_acc(std::integral_constant<int, 4>{}, p0, n);
+            if (maxn <= STAC_RT) return range_acc(std::integral_constant<int, STAC_RT>{}, p0, n);
+            return range_acc(std::integral_constant<int, 24>{}, p0, n);
+        };
+        // (a task out of registers -- latency kernels, the lane's first tasks: LATPIN; maxn: the round's longest range)
+        auto range_task_pinned = [&](const auto &tp, float *CBx, const int maxn) {
+            CBx[tp.dst] = range_acc_by(maxn, CBx + tp.src + kXf * tp.lo, tp.hi - tp.lo);
         };
         auto range_task = [&](const int t, float *CBx) {
             const int r = t / 6, k = t - 6 * r;
@@ -968,17 +981,8 @@ void q_phase_kernel(const QArgs a_in) {
             const float *src = CBx + H.c_sw + co;
             float acc = 0.f;
             if constexpr (SPEC != 0) {
-                // (latency kernels: a lone wavefront waits out every LDS round trip, so eight sites per trip and no remainder loop --
-                //  the sites behind the range's end are read again at its last site and their additions dropped: the same sum)
-                const int last = rr.hi - 1;
-                constexpr int RT = STAC_RT;
-                for (int i = rr.lo; i < rr.hi; i += RT) {
-                    float v[RT];
-#pragma unroll
-                    for (int u = 0; u < RT; ++u) v[u] = src[kXf * min(i + u, last)];
-#pragma unroll
-                    for (int u = 0; u < RT; ++u) acc = i + u <= last ? acc + v[u] : acc;
-                }
+                // (latency kernels: a lone wavefront waits out every LDS round trip, so twelve sites per trip and no remainder loop)
+                acc = range_acc(std::integral_constant<int, STAC_RT>{}, src + kXf * rr.lo, rr.hi - rr.lo);
             } else {
                 int i = rr.lo;
                 for (; i + 4 <= rr.hi; i += 4) {  // four in flight per LDS round trip
@@ -1396,11 +1400,13 @@ void q_phase_kernel(const QArgs a_in) {
                         const V3 crefx = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_bx + kXf);
                         if constexpr (LATPIN) {  // (the lane's first two tasks / the helper's one out of registers)
                             const int base = SOLO ? 0 : 6;
+                            // (the ranges are sorted longest first: a round's first task has its longest range)
+                            const RangeRec r0 = rrec[0], ra = rrec[base / 6], rb = rrec[min((base + 64) / 6, H.nrange - 1)];
                             if (mine) {
-                                if (base + lane < 6 * H.nrange) range_task_pinned(pin_t[0], CBx);
-                                if (base + lane + 64 < 6 * H.nrange) range_task_pinned(pin_t[1], CBx);
+                                if (base + lane < 6 * H.nrange) range_task_pinned(pin_t[0], CBx, ra.hi - ra.lo);
+                                if (base + lane + 64 < 6 * H.nrange) range_task_pinned(pin_t[1], CBx, rb.hi - rb.lo);
                                 for (int t = base + lane + 128; t < 6 * H.nrange; t += 64) range_task(t, CBx);
-                            } else if (lane < 6) range_task_pinned(pin_t[2], CBx);
+                            } else if (lane < 6) range_task_pinned(pin_t[2], CBx, r0.hi - r0.lo);
                         } else {
                         if (mine) { for (int t = (SOLO ? 0 : 6) + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
                         else if (lane < 6) range_task(lane, CBx);
