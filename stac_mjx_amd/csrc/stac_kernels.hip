@@ -1416,9 +1416,14 @@ void q_phase_kernel(const QArgs a_in) {
                         PROF_TICK(9);
 #endif
                         if constexpr (LATPIN) {
+                            // (the free root -- lean kernels: joint 0, qpos 0 .. 6, range 0 --: one component per lane, its four divisions
+                            //  side by side, where the wavefront that takes it has nothing else in this round: the neighbour wavefront of
+                            //  the four-wavefront kernels, whose other lanes idle)
+                            const bool free0_lanes = !SOLO && !mine;
+                            if (free0_lanes && lane < 7) gx[lane] = free0_gradient(CBx, crefx, CBx + H.c_rw, 0, lane);
                             if (lane < H.naj) {  // first round: the lane's joint out of registers
                                 const bool on_longest = pin_g.rw == H.c_rw;  // (range 0)
-                                if (SOLO || on_longest != mine) joint_gradient(pin_g.j, CBx, crefx, gx, true);
+                                if ((SOLO || on_longest != mine) && !(free0_lanes && pin_g.j == 0)) joint_gradient(pin_g.j, CBx, crefx, gx, true);
                             }
                         }
                         for (int j = lane + (LATPIN ? 64 : 0); j < H.naj; j += 64) {
@@ -1430,25 +1435,24 @@ void q_phase_kernel(const QArgs a_in) {
                 PROF_TICK(5);  // latency mode: gradient pass of the two chosen evaluations (owner waves)
                 chain_sync();
                 PROF_TICK(6);  // latency mode: wait for the gradients
-                float gnext[NQR];
+                // (straight-line: both vectors are read at a valid index and selected, the accepted point is computed once -- the branches
+                //  round every register's loads and the second evaluation of the clip cost a lone wavefront ~50 instructions per trip)
+                float gnext[NQR], xacc[NQR];
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
-                    const bool on = e < nq && ((mbits >> r) & 1u);
-                    gnew[r] = on ? gxa[e] : 0.0f;
-                    gnext[r] = on ? gxn[e] : 0.0f;
+                    const bool in = e < nq, on = in && ((mbits >> r) & 1u);
+                    const float ga = gxa[in ? e : 0], gb = gxn[in ? e : 0];
+                    gnew[r] = on ? ga : 0.0f;
+                    gnext[r] = on ? gb : 0.0f;
                 }
                 float t0[NQR];
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
-                    float a0 = 0.0f;
-                    if (e < nq) {
-                        const float xr = clipf(FMA(-eacc, g[r], y[r]), LB(r, e), UB(r, e));
-                        const float d = clipf(xr - gnew[r], LB(r, e), UB(r, e)) - xr;
-                        a0 = d * d;
-                    }
-                    t0[r] = a0;
+                    xacc[r] = clipf(FMA(-eacc, g[r], y[r]), LB(r, e), UB(r, e));
+                    const float d = clipf(xacc[r] - gnew[r], LB(r, e), UB(r, e)) - xacc[r];
+                    t0[r] = e < nq ? d * d : 0.0f;
                 }
                 const float e2 = group_tree_sum<G, NQR>(t0);  // the same value in every role
                 const float fx_c = xc[4 * cs + 1];
@@ -1460,7 +1464,7 @@ void q_phase_kernel(const QArgs a_in) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
                     const int e = r * G + lg;
-                    const float cr = e < nq ? clipf(FMA(-eacc, g[r], y[r]), LB(r, e), UB(r, e)) : x[r];
+                    const float cr = e < nq ? xacc[r] : x[r];
                     const float d = cr - x[r];
                     y[r] = FMA(spec_beta, d, cr);
                     x[r] = cr;
