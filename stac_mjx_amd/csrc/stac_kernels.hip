@@ -240,8 +240,8 @@ void q_phase_kernel(const QArgs a_in) {
     // keypoints of a frame: this lane's sites into registers, or the whole frame into LDS
     // (TripCtx: what the chain-level helpers below need of the launch and the lane, handed in by the caller, so that nothing
     //  they use has to stay live across the trip loop: see "Launch arguments inside the trip loop" below)
-    struct TripCtx { int lg, nq, K; float *kpl; const float *lbv, *ubv, *qpos0; };
-    const TripCtx cx0{lg, nq, K, kpl, lbv, ubv, qpos0};
+    struct TripCtx { int lg, nq, K; float *kpl; const float *lbv, *ubv, *qpos0; const uint32_t *MB; };
+    const TripCtx cx0{lg, nq, K, kpl, lbv, ubv, qpos0, MB};
     auto load_kp = [&](const auto &a, const TripCtx &cx, const size_t base) {
         const int lg = cx.lg, K = cx.K;
         float *const kpl = cx.kpl;
@@ -280,6 +280,9 @@ void q_phase_kernel(const QArgs a_in) {
     // they drop out of every norm and never move, and the solver transition of a root fast trip looks at register 0 only.
     // (They are constant over a chain's root solves, so this is settled when the chain starts.)
     bool tail_ok = true;
+    // the qs_to_opt bits of the running solve for this lane's coordinates (MB[kind][lane]): carried across the trips of a solve, read
+    // again where the kind changes (end of a solve, next chain) -- not at the top of every trip, where the staging waits for it
+    uint32_t mbits_c = 0;
     auto check_tail = [&](const auto &a, const TripCtx &cx) {
         const int lg = cx.lg, nq = cx.nq;
         const float *const lbv = cx.lbv, *const ubv = cx.ubv;
@@ -312,6 +315,7 @@ void q_phase_kernel(const QArgs a_in) {
         load_kp(a, cx, kp_chain);
         st = ST_VG_Y;
         ql_fresh = false;
+        mbits_c = cx.MB[kind * G + lg];
         if (!SPEC && a.root_fast > 0) check_tail(a, cx);
     };
     if (resuming) {
@@ -344,6 +348,10 @@ void q_phase_kernel(const QArgs a_in) {
         }
         sites1 = !SPEC && a.root_fast > 0 && !__any(cnt > 1);
     }
+    mbits_c = MB[kind * G + lg];
+    // (the coordinates that have a gradient entry at all -- the row behind the kinds' --: constant for the launch)
+    uint32_t act_bits = MB[nkinds * G + lg];
+    asm volatile("" : "+v"(act_bits));
     // ---- lean latency kernels: what a lane reads from the plan in EVERY trip, kept in registers (round 6) ---------------------------
     // A lone wavefront waits out every LDS round trip, and the per-item phases of a trip begin with two or three DEPENDENT ones: the item's
     // record (which joint / site / rotation is this lane's?), then the addresses in it, then the data.  The lane's items never change, and
@@ -354,12 +362,23 @@ void q_phase_kernel(const QArgs a_in) {
 #else
     constexpr bool LATPIN = false;
 #endif
-    constexpr int PJ = LATPIN ? (G == 32 ? 2 : 3) : 1;  // rounds of the pre-pass whose joints are pinned (rodent: all of them)
+    // (the 16-lane lean throughput kernels have a dozen registers to spare under their cap: the site records as well, +1 %)
+#ifndef STAC_NO_THRPIN
+    constexpr bool SITEPIN = LATPIN || (LEAN && SPEC == 0 && G == 16);
+#else
+    constexpr bool SITEPIN = LATPIN;
+#endif
+#ifndef STAC_NO_THRPIN2
+    constexpr bool PREPIN = LATPIN || (LEAN && SPEC == 0 && G == 16);  // (and the pre-pass joints: +0.8 % on 100 000 frames, 164 of 168 registers)
+#else
+    constexpr bool PREPIN = LATPIN;
+#endif
+    constexpr int PJ = PREPIN ? (G == 32 ? 2 : 3) : 1;  // rounds of the pre-pass whose joints are pinned (rodent: all of them)
     float4 pin_sr[NSR];      // SiteRec of the lane's sites
     int pin_s3[NSR];         // their body position / quaternion words under the full program
     int pin_jad[PJ], pin_jout[PJ];
     float pin_jq0[PJ], pin_jax[PJ][3];
-    if constexpr (LATPIN) {
+    if constexpr (SITEPIN) {
         const int *site3f = reinterpret_cast<const int *>(P + H.off3_prog) + 16 * (H.fk3_cap1 + 2) + 4 * H.fk3_cap2 + 4 * H.fk3_cap3;
 #pragma unroll
         for (int r = 0; r < NSR; ++r) {
@@ -368,6 +387,8 @@ void q_phase_kernel(const QArgs a_in) {
             pin_s3[r] = site3f[k];
             asm volatile("" : "+v"(pin_sr[r].x), "+v"(pin_sr[r].y), "+v"(pin_sr[r].z), "+v"(pin_sr[r].w), "+v"(pin_s3[r]));
         }
+    }
+    if constexpr (PREPIN) {
 #pragma unroll
         for (int u = 0; u < PJ; ++u) {
             const int j = min(lg + 1 + u * G, H.naj - 1);  // (a lane without a joint in this round repeats the last one: the same value to the same words)
@@ -384,7 +405,7 @@ void q_phase_kernel(const QArgs a_in) {
     constexpr int PR2 = 3;
     float4 pin_t2[LATPIN ? PR2 : 1];
     struct GPin { int ad, rw, jw, j; float ax, ay, az; };  // qpos address, word of the range sum, anchor / pre-joint quaternion words, joint
-    struct TPin { int lo, hi, src, dst; };                  // site range, word of the first site's component, word of the sum
+    struct TPin { int lo, hi, src, dst, maxn; };            // site range, word of the first site's component, word of the sum; the round's longest range
     GPin pin_g = {};
     TPin pin_t[LATPIN ? 3 : 1] = {};
     if constexpr (LATPIN) {
@@ -415,8 +436,10 @@ void q_phase_kernel(const QArgs a_in) {
                 const int t = u < 2 ? min(base + lane + 64 * u, 6 * H.nrange - 1) : min(lane, 5);
                 const int r = t / 6, k = t - 6 * r;
                 const int co = k < 3 ? k : kXq + k - 3;
-                pin_t[u] = TPin{rrec_p[r].lo, rrec_p[r].hi, H.c_sw + co, H.c_rw + kXf * r + co};
-                asm volatile("" : "+v"(pin_t[u].lo), "+v"(pin_t[u].hi), "+v"(pin_t[u].src), "+v"(pin_t[u].dst));
+                // (the ranges are sorted longest first: a round's first task has its longest range)
+                const int r_first = u < 2 ? min((base + 64 * u) / 6, H.nrange - 1) : 0;
+                pin_t[u] = TPin{rrec_p[r].lo, rrec_p[r].hi, H.c_sw + co, H.c_rw + kXf * r + co, rrec_p[r_first].hi - rrec_p[r_first].lo};
+                asm volatile("" : "+v"(pin_t[u].lo), "+v"(pin_t[u].hi), "+v"(pin_t[u].src), "+v"(pin_t[u].dst), "+v"(pin_t[u].maxn));
             }
         }
     }
@@ -487,7 +510,7 @@ void q_phase_kernel(const QArgs a_in) {
         float *const bx = CB + H.c_bx, *const ja = CB + H.c_ja, *const jn = CB + H.c_jn, *const qsv = CB + H.c_qsv;
         float *const sw = CB + H.c_sw, *const gg = sw, *const r2 = CB + H.c_r2;
         float *const qe = sw, *const kpl = CB + H.c_kp;
-        const TripCtx cx{lg, nq, K, kpl, lbv, ubv, P + H.off_qpos0};
+        const TripCtx cx{lg, nq, K, kpl, lbv, ubv, P + H.off_qpos0, MB};
         // lean kernels (split kinematics, PlanHeader::fk3): word of the root position inside a chain's region (behind the slots of P3)
         const int root_w = LEAN ? H.c3_pb + 12 * H.fk3_cap3 : 0;
         if (!SPEC && a.ctl && !a.resume) {
@@ -547,7 +570,7 @@ void q_phase_kernel(const QArgs a_in) {
         }
         const int st_in = st;
         const bool live_in = st_in != ST_DONE && st_in != ST_WAIT && (SPEC || st_in != ST_NEXT);
-        const uint32_t mbits = MB[kind * G + lg];
+        const uint32_t mbits = mbits_c;
         // A line-search candidate that is accepted becomes x_next, whose gradient the stopping test
         // needs (the oracle's separate VG_X evaluation runs the very same FK).  The step size doubles
         // after every iteration, so the first candidate is almost always rejected and the second
@@ -704,7 +727,7 @@ void q_phase_kernel(const QArgs a_in) {
                 // joint again: the same value to the same words.
                 // (throughput kernels: a lone wavefront of the latency kernels pays per instruction, dependent or not)
                 constexpr int U = SPEC != 0 ? (G == 32 ? 2 : 1) : (G == 16 ? 3 : 2);
-                if constexpr (LATPIN) {  // (the lane's joints of the first PJ rounds out of registers: LATPIN, above)
+                if constexpr (PREPIN) {  // (the lane's joints of the first PJ rounds out of registers: LATPIN, above)
 #pragma unroll
                     for (int u = 0; u < PJ; ++u) {
                         if (u > 0 && 1 + u * G >= H.naj) break;  // (wave-uniform: no joint left for any lane)
@@ -714,7 +737,7 @@ void q_phase_kernel(const QArgs a_in) {
                         *reinterpret_cast<float4 *>(CB + pin_jout[u]) = float4{cs, pin_jax[u][0] * sn, pin_jax[u][1] * sn, pin_jax[u][2] * sn};
                     }
                 }
-                for (int j0 = lg + 1 + (LATPIN ? PJ * G : 0); j0 < H.naj; j0 += U * G) {
+                for (int j0 = lg + 1 + (PREPIN ? PJ * G : 0); j0 < H.naj; j0 += U * G) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int j = min(j0 + u * G, H.naj - 1);
@@ -793,14 +816,14 @@ void q_phase_kernel(const QArgs a_in) {
         // (f, (x - c) x f) goes to its place in DFS-site order
         auto site_term = [&](const int k, const float kx, const float ky, const float kz, const bool tw, const int rr = -1) -> float {
             float4 sr;
-            if constexpr (LATPIN) sr = pin_sr[rr < 0 ? 0 : rr];  // (the latency kernels call it with the round: site_regs)
+            if (SITEPIN && rr >= 0) sr = pin_sr[rr < 0 ? 0 : rr];  // (called with the round: the record out of registers)
             else sr = lds4(srec + 4 * k);
             const int ss = __builtin_bit_cast(int, sr.w);
             V3 bpos_w;
             Q4 bquat_w;
             if constexpr (LEAN) {
                 int s3;
-                if constexpr (LATPIN) {
+                if (SITEPIN && rr >= 0) {
                     s3 = pin_s3[rr < 0 ? 0 : rr];
                     if (n_ml_root > 0) s3 = site3[k];  // (wave-uniform: a root pass ran the pruned program)
                 } else {
@@ -1151,7 +1174,7 @@ void q_phase_kernel(const QArgs a_in) {
                 }
             }
             wave_sync();
-            const uint32_t abits = SPEC ? mbits : (MB[nkinds * G + lg] & mbits);  // optimised coordinates that HAVE a gradient entry
+            const uint32_t abits = SPEC ? mbits : (act_bits & mbits);  // optimised coordinates that HAVE a gradient entry
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;
@@ -1400,13 +1423,11 @@ void q_phase_kernel(const QArgs a_in) {
                         const V3 crefx = LEAN ? ld3(CBx + root_w) : ld_tpos(CBx + H.c_bx + kXf);
                         if constexpr (LATPIN) {  // (the lane's first two tasks / the helper's one out of registers)
                             const int base = SOLO ? 0 : 6;
-                            // (the ranges are sorted longest first: a round's first task has its longest range)
-                            const RangeRec r0 = rrec[0], ra = rrec[base / 6], rb = rrec[min((base + 64) / 6, H.nrange - 1)];
                             if (mine) {
-                                if (base + lane < 6 * H.nrange) range_task_pinned(pin_t[0], CBx, ra.hi - ra.lo);
-                                if (base + lane + 64 < 6 * H.nrange) range_task_pinned(pin_t[1], CBx, rb.hi - rb.lo);
+                                if (base + lane < 6 * H.nrange) range_task_pinned(pin_t[0], CBx, pin_t[0].maxn);
+                                if (base + lane + 64 < 6 * H.nrange) range_task_pinned(pin_t[1], CBx, pin_t[1].maxn);
                                 for (int t = base + lane + 128; t < 6 * H.nrange; t += 64) range_task(t, CBx);
-                            } else if (lane < 6) range_task_pinned(pin_t[2], CBx, r0.hi - r0.lo);
+                            } else if (lane < 6) range_task_pinned(pin_t[2], CBx, pin_t[2].maxn);
                         } else {
                         if (mine) { for (int t = (SOLO ? 0 : 6) + lane; t < 6 * H.nrange; t += 64) range_task(t, CBx); }
                         else if (lane < 6) range_task(lane, CBx);
@@ -1501,7 +1522,8 @@ void q_phase_kernel(const QArgs a_in) {
 #endif
             const int nq = H.nq, K = H.K;
             const int *const quat_adr = reinterpret_cast<const int *>(P + H.off_quat_adr);
-            const TripCtx cx{lg, nq, K, CB + H.c_kp, P + H.off_lb, P + H.off_ub, P + H.off_qpos0};
+            const TripCtx cx{lg, nq, K, CB + H.c_kp, P + H.off_lb, P + H.off_ub, P + H.off_qpos0,
+                             reinterpret_cast<const uint32_t *>(lds + ((H.total_words - H.plan_skip + 3) & ~3))};
             if (ending) {
 #pragma unroll
                 for (int r = 0; r < NQR; ++r) {
@@ -1609,6 +1631,7 @@ void q_phase_kernel(const QArgs a_in) {
                     }
                 }
             }
+            mbits_c = cx.MB[kind * G + lg];  // (the next solve's bits: kind has moved on for the lanes that ended one)
             wave_sync();
         }
         PROF_TICK(9);  // end of solve
