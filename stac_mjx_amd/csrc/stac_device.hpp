@@ -990,13 +990,25 @@ __device__ __forceinline__ float fk3_restart_value(const float *base, const int 
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + ((unsigned)e << 2));  // (bits 30, 31 leave: one v_lshl_add)
 }
 __device__ __forceinline__ int2 lds2i(const float *p) { return *reinterpret_cast<const int2 *>(p); }
-__device__ __forceinline__ void fk3_p1(const float *T1, const int nb, float *CBc, const Fk3Lane &L) {
+// (Fk3Head: the first two records of the lane's position, which the lean latency kernels keep in registers -- the pass then starts with
+//  its quaternions' round trip, not with the records' and then theirs)
+struct Fk3Head { int ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, pa0, pa1, pb0, pb1; };  // (plain words: a struct of vectors went through scratch)
+__device__ __forceinline__ Fk3Head fk3_p1_head(const float *T1, const Fk3Lane &L) {
+    const float *rp = T1 + 4 * L.pp, *ep = T1 + 16 + 2 * L.pp;
+    const int4 a = lds4i(rp), b = lds4i(rp + 24);
+    const int2 c = lds2i(ep), d = lds2i(ep + 24);
+    return Fk3Head{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, d.x, d.y};
+}
+__device__ __forceinline__ void fk3_p1(const float *T1, const int nb, float *CBc, const Fk3Lane &L, const bool use_head, const Fk3Head head) {
     float *base = CBc + L.c;
     const float *rp = T1 + 4 * L.pp, *ep = T1 + 16 + 2 * L.pp;
-    int4 Ra = lds4i(rp);
-    int2 Pa = lds2i(ep);
-    int4 Rb = lds4i(rp + 24);
-    int2 Pb = lds2i(ep + 24);
+    int4 Ra, Rb;
+    int2 Pa, Pb;
+    if (use_head) {  // (wave-uniform)
+        Ra = int4{head.ra0, head.ra1, head.ra2, head.ra3}; Rb = int4{head.rb0, head.rb1, head.rb2, head.rb3};
+        Pa = int2{head.pa0, head.pa1}; Pb = int2{head.pb0, head.pb1};
+    }
+    else { Ra = lds4i(rp); Pa = lds2i(ep); Rb = lds4i(rp + 24); Pb = lds2i(ep + 24); }
     float qa = base[Ra.x], qb = base[Ra.y];
     float rl = fk3_restart_value(base, Pa.y);
     float qc = 0.0f;
@@ -1091,12 +1103,18 @@ __device__ __forceinline__ void fk3_p2_pinned(const float4 (&tk)[NR], const floa
 // Everything a block reads is requested while the block before it runs -- its four operands, its restart value (the host schedules a
 // restart at least five steps behind the step that wrote the value: fk3_schedule); the restart words come three blocks ahead -- so a
 // lone wavefront pays the LDS round trip once per pass, not once per step.
-__device__ __forceinline__ void fk3_p3(const int *T3, const int nb, float *CBc, const int pb, const Fk3Lane &L) {
+__device__ __forceinline__ void fk3_p1(const float *T1, const int nb, float *CBc, const Fk3Lane &L) {
+    fk3_p1(T1, nb, CBc, L, false, Fk3Head{});
+}
+__device__ __forceinline__ void fk3_p3(const int *T3, const int nb, float *CBc, const int pb, const Fk3Lane &L, const bool use_head = false,
+                                       const int h0 = 0, const int h1 = 0, const int h2 = 0) {
     const int cc = L.c ? L.c - 1 : 0;  // (lane 0 of a quad doubles lane 1: the same loads, the same values stored to the same words)
     const float *base = CBc + cc;
     float *slot = CBc + pb + 3 * L.pp + cc;
     const int *rp = T3 + L.pp;
-    int e0 = rp[0], e1 = rp[4], e2 = rp[8];  // (the words two blocks ahead of their use: no block waits for the one it requested last)
+    // (the words two blocks ahead of their use: no block waits for the one it requested last; head3: the first three out of registers)
+    int e0 = h0, e1 = h1, e2 = h2;
+    if (!use_head) { e0 = rp[0]; e1 = rp[4]; e2 = rp[8]; }  // (wave-uniform)
     float v0 = slot[0], v1 = slot[12], v2 = slot[24], v3 = slot[36];
     float rl = fk3_restart_value(base, e0);
     float p = 0.0f;

@@ -404,6 +404,8 @@ void q_phase_kernel(const QArgs a_in) {
     // tasks of its first two (the lanes of a chain's wavefronts take joint `lane` / task `lane`, `lane + 64`)
     constexpr int PR2 = 3;
     float4 pin_t2[LATPIN ? PR2 : 1];
+    Fk3Head pin_h1 = {};   // P1's first two records of the lane's position, P3's first three restart words (full program)
+    int pin_h3[3] = {0, 0, 0};
     struct GPin { int ad, rw, jw, j; float ax, ay, az; };  // qpos address, word of the range sum, anchor / pre-joint quaternion words, joint
     struct TPin { int lo, hi, src, dst, maxn; };            // site range, word of the first site's component, word of the sum; the round's longest range
     GPin pin_g = {};
@@ -411,6 +413,13 @@ void q_phase_kernel(const QArgs a_in) {
     if constexpr (LATPIN) {
         const float *T2f = P + H.off3_prog + 16 * (H.fk3_cap1 + 2);
         const int n2f = (int)((unsigned)H.fk3_n >> 16);
+        {
+            const Fk3Lane L3 = fk3_lane(lg & 15);
+            pin_h1 = fk3_p1_head(P + H.off3_prog, L3);
+            const int *T3f = reinterpret_cast<const int *>(T2f + 4 * H.fk3_cap2) + L3.pp;
+            pin_h3[0] = T3f[0]; pin_h3[1] = T3f[4]; pin_h3[2] = T3f[8];
+            asm volatile("" : "+v"(pin_h3[0]), "+v"(pin_h3[1]), "+v"(pin_h3[2]));
+        }
 #pragma unroll
         for (int r = 0; r < PR2; ++r) {
             pin_t2[r] = lds4(T2f + 4 * min(r * G + lg, n2f - 1));
@@ -789,12 +798,12 @@ void q_phase_kernel(const QArgs a_in) {
 #else
             if constexpr (LATPIN) {
                 const Fk3Lane L3 = fk3_lane(lg & 15);
-                if (G == 16 || lg < 16) fk3_p1(G3.T1, G3.n1 >> 1, CB, L3);
+                if (G == 16 || lg < 16) fk3_p1(G3.T1, G3.n1 >> 1, CB, L3, !rootp, pin_h1);
                 wave_sync();
                 if (rootp) fk3_p2<false>(G3.T2, G3.n2, CB, lg, G);  // (a root pass runs the pruned program's rotations)
                 else fk3_p2_pinned<PR2>(pin_t2, G3.T2, G3.n2, CB, lg, G);
                 wave_sync();
-                if (G == 16 || lg < 16) fk3_p3(G3.T3, G3.n3 >> 2, CB, H.c3_pb, L3);
+                if (G == 16 || lg < 16) fk3_p3(G3.T3, G3.n3 >> 2, CB, H.c3_pb, L3, !rootp, pin_h3[0], pin_h3[1], pin_h3[2]);
                 wave_sync();
             } else {
                 fk3_run<(SPEC == 0 && G == 16)>(G3, CB, H.c3_pb, lg, G);
