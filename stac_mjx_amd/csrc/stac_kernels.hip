@@ -350,8 +350,12 @@ void q_phase_kernel(const QArgs a_in) {
     }
     mbits_c = MB[kind * G + lg];
     // (the coordinates that have a gradient entry at all -- the row behind the kinds' --: constant for the launch)
-    uint32_t act_bits = MB[nkinds * G + lg];
-    asm volatile("" : "+v"(act_bits));
+    // (lean kernels; the generic ones, some of them at their register cap, read it where they use it)
+    uint32_t act_bits = 0;
+    if constexpr (LEAN) {
+        act_bits = MB[nkinds * G + lg];
+        asm volatile("" : "+v"(act_bits));
+    }
     // ---- lean latency kernels: what a lane reads from the plan in EVERY trip, kept in registers (round 6) ---------------------------
     // A lone wavefront waits out every LDS round trip, and the per-item phases of a trip begin with two or three DEPENDENT ones: the item's
     // record (which joint / site / rotation is this lane's?), then the addresses in it, then the data.  The lane's items never change, and
@@ -527,6 +531,7 @@ void q_phase_kernel(const QArgs a_in) {
             // latency kernel (its state is complete at this point: x, y, q0 and a dozen scalars)
             // (looked at every eighth iteration: the counter lives in L2)
             if (__any(st == ST_VG_Y && (iter & 7) == 0)) {
+                // (using the count requested at the previous look, so that the trip that looks does not wait for L2: measured 1.7 % SLOWER)
                 const int done_cnt = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (st == ST_VG_Y && (iter & 7) == 0 && done_cnt >= a.ctl[1]) {
                     int slot = 0;
@@ -1183,7 +1188,7 @@ void q_phase_kernel(const QArgs a_in) {
                 }
             }
             wave_sync();
-            const uint32_t abits = SPEC ? mbits : (act_bits & mbits);  // optimised coordinates that HAVE a gradient entry
+            const uint32_t abits = SPEC ? mbits : ((LEAN ? act_bits : MB[nkinds * G + lg]) & mbits);  // optimised coordinates that HAVE a gradient entry
 #pragma unroll
             for (int r = 0; r < NQR; ++r) {
                 const int e = r * G + lg;

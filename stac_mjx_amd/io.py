@@ -154,7 +154,7 @@ def _n_threads() -> int:
         local_world = max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1)
     except ValueError:
         local_world = 1
-    return max(1, min(n // local_world, 128))
+    return max(1, min(n // local_world, 64))
 
 
 def _map_window(pool, fn, jobs, window=None):
@@ -211,45 +211,60 @@ def _npy_bytes_header(arr) -> bytes:
     return b.getvalue()
 
 
-def _crc32_combine(crc1: int, crc2: int, len2: int) -> int:
-    """CRC-32 of A + B from crc32(A), crc32(B) and len(B): appending len2 zero bytes to A is a linear map of the CRC register over
-    GF(2) (a 32 x 32 bit matrix, squared log2(len2) times), then the two CRCs add.  Lets every deflate block carry its own CRC."""
-    if len2 <= 0:
-        return crc1
+_CRC_SHIFT = {}  # len2 -> the 32 x 32 GF(2) matrix (32 column words) that appends len2 zero bytes to a CRC-32 register
 
-    def times(mat, vec):
+
+def _crc32_shift_matrix(len2: int):
+    """Appending zero bytes to a message is a linear map of its CRC register over GF(2); the map for len2 bytes by repeated squaring
+    of the one-bit map (cached per length: every deflate block but a member's last has the same)."""
+    mat = _CRC_SHIFT.get(len2)
+    if mat is not None:
+        return mat
+
+    def times(m, vec):
         out, i = 0, 0
         while vec:
             if vec & 1:
-                out ^= mat[i]
+                out ^= m[i]
             vec >>= 1
             i += 1
         return out
 
-    def square(mat):
-        return [times(mat, mat[i]) for i in range(32)]
+    def mul(m1, m2):  # m1 after m2
+        return [times(m1, m2[i]) for i in range(32)]
 
-    odd = [0xEDB88320] + [1 << (i - 1) for i in range(1, 32)]  # one zero BIT appended (reflected polynomial)
-    even = square(odd)   # two bits
-    odd = square(even)   # four bits
+    one_bit = [0xEDB88320] + [1 << (i - 1) for i in range(1, 32)]  # one zero BIT appended (reflected polynomial)
+    power = one_bit
+    for _ in range(3):
+        power = mul(power, power)  # eight bits = one zero byte
+    result = [1 << i for i in range(32)]  # identity
     n = len2
-    while True:  # (first pass: eight bits = one zero byte per unit of n)
-        even = square(odd)
+    while n:
         if n & 1:
-            crc1 = times(even, crc1)
+            result = mul(power, result)
         n >>= 1
-        if not n:
-            break
-        odd = square(even)
-        if n & 1:
-            crc1 = times(odd, crc1)
-        n >>= 1
-        if not n:
-            break
-    return (crc1 ^ crc2) & 0xFFFFFFFF
+        if n:
+            power = mul(power, power)
+    if len(_CRC_SHIFT) < 64:
+        _CRC_SHIFT[len2] = result
+    return result
 
 
-def _npz_write_parallel(path, members: dict, pool, level: int = 6) -> None:
+def _crc32_combine(crc1: int, crc2: int, len2: int) -> int:
+    """CRC-32 of A + B from crc32(A), crc32(B) and len(B): lets every deflate block carry its own CRC."""
+    if len2 <= 0:
+        return crc1
+    mat = _crc32_shift_matrix(len2)
+    out, i = 0, 0
+    while crc1:
+        if crc1 & 1:
+            out ^= mat[i]
+        crc1 >>= 1
+        i += 1
+    return (out ^ crc2) & 0xFFFFFFFF
+
+
+def _npz_write_parallel(path, members: dict, pool, level: int = _H5_GZIP_LEVEL) -> None:
     """``np.savez_compressed`` with the deflate work spread over the pool: every member is a plain ZIP_DEFLATED entry whose
     stream is the concatenation of independently compressed blocks (each ended with a sync flush, the last one finished), so
     ``np.load`` / ``zipfile`` read it like any other .npz.  ZIP64 throughout (members can exceed 4 GiB).  The blocks of ALL members
