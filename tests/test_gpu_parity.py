@@ -640,6 +640,41 @@ def test_lm_q_phase_equals_oracle_lm_bit_for_bit(rodent_setup, rodent_mocap, lan
     assert it < 60, it
 
 
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_lm_fruitfly_bit_exact_and_mouse_refused(fly_setup, mouse_setup, lanes):
+    """Round 6: the optional LM solver on BASELINE configs[4]'s model (fruit fly: oriented leg bodies, 43 coordinates, no root
+    optimisation, six part groups) equals the oracle's LM bit for bit and fits the markers at least as well as the PG solver; the mouse
+    (230 coordinates: 12.5 KB of LDS per chain times its path depth) is beyond the solver's capacity -- LDS per CU / 192 coordinates -- and is REFUSED with an error that says so (never mis-run)."""
+    from oracle import Oracle
+    from stac_mjx_amd.engine import Engine, StacHipError
+
+    fs = fly_setup
+    t = fs.tables
+    orc = Oracle(t, tol=1e-4)
+    rng = np.random.default_rng(31)
+    qt = t.qpos0[None] + np.clip(rng.normal(0, 0.15, (8, t.nq)), -0.3, 0.3).astype(np.float32)
+    qt[:, 3:7] = t.qpos0[3:7]
+    kp = np.stack([orc.fk(q)["site_xpos"].reshape(-1) for q in qt]).astype(np.float32)
+    kp = (kp + rng.normal(0, 1e-3, kp.shape)).astype(np.float32).reshape(4, 2, -1)
+    eng = Engine(t, fs.lb, fs.ub, tol=1e-4, solver="lm", lm_maxiter=30, lanes_per_chain=lanes)
+    res = eng.q_phase(kp, part_masks=fs.part_masks)
+    ref = orc.ik_clips_lm(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 0, 7, do_root_opt=False, maxiter=30)
+    np.testing.assert_array_equal(_np(res["qpos"]).view(np.uint32), ref["qpos"].view(np.uint32))
+    np.testing.assert_array_equal(_np(res["frame_error"]).view(np.uint32), ref["frame_error"].view(np.uint32))
+    np.testing.assert_array_equal(_np(res["counters"]).astype(np.uint32), ref["counters"])
+    pg = orc.ik_clips(kp, fs.lb, fs.ub, fs.part_masks, fs.trunk_kps, 0, 7, do_root_opt=False)
+    tgt = kp.reshape(4, 2, t.nsite, 3)
+    assert np.linalg.norm(_np(res["marker_sites"]) - tgt, axis=-1).mean() <= np.linalg.norm(pg["marker_sites"] - tgt, axis=-1).mean() + 1e-5
+    eng.close()
+    ms = mouse_setup
+    engm = Engine(ms.tables, ms.lb, ms.ub, tol=1e-4, solver="lm", lm_maxiter=5, lanes_per_chain=lanes)
+    kpm = np.zeros((2, 1, 3 * ms.tables.nsite), np.float32)
+    with pytest.raises(StacHipError, match="LM q_phase kernel limits|192 optimised coordinates"):
+        engm.q_phase(kpm, part_masks=ms.part_masks, trunk_kps=ms.trunk_kps, root_kp_idx=ms.root_kp_idx, root_dims=ms.root_dims,
+                     do_root_opt=ms.do_root_opt)
+    engm.close()
+
+
 @pytest.mark.parametrize("seed,free_root", [(0, True), (1, False), (2, True), (5, False)])
 def test_lm_ball_and_slide_models_bit_exact(seed, free_root):
     """Round 5: ball joints in the LM solver (four raw quaternion coordinates per joint, columns in the frame the rotation is applied
