@@ -29,7 +29,13 @@ done
   run "100k frames, n_frames_per_clip=1" --frames 100000 --steps 3 --warmup 1
   run "125k frames, n_frames_per_clip=250 (config 4 share)" --frames 125000 --frames-per-clip 250 --steps 1 --warmup 1
   run "250k frames, n_frames_per_clip=250" --frames 250000 --frames-per-clip 250 --steps 1 --warmup 1
+  run "375k frames, n_frames_per_clip=250 (1500 chains: the N = 3 share of configs[3])" --frames 375000 --frames-per-clip 250 --steps 1 --warmup 1
+  run "500k frames, n_frames_per_clip=250 (2000 chains: the N = 2 share of configs[3])" --frames 500000 --frames-per-clip 250 --steps 1 --warmup 1
+  run "750k frames, n_frames_per_clip=250 (3000 chains)" --frames 750000 --frames-per-clip 250 --steps 1 --warmup 1
   run "fly 10k frames" --model fly --steps 5 --warmup 2
+  run "fly 25k frames at 250 per clip (config 5: the per-GPU share of 200k frames on 8 GPUs)" --model fly --frames 25000 --frames-per-clip 250 --steps 2 --warmup 1
+  run "fly 25k frames, n_frames_per_clip=1" --model fly --frames 25000 --steps 3 --warmup 1
+  run "LM 10k frames, 40 steps per solve" --solver lm --lm-maxiter 40 --steps 10 --warmup 3
   run "mouse 10k frames" --model mouse --steps 2 --warmup 1
   run "LM 10k frames" --solver lm --steps 10 --warmup 3
   run "LM 100k frames" --solver lm --frames 100000 --steps 3 --warmup 1
@@ -46,7 +52,7 @@ done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 profiles/tools/valu_issue_micro.hip -o /tmp/valu_issue_micro && /tmp/valu_issue_micro > $OUT/valu_issue_micro.txt 2>&1
 bash profiles/tools/suite_coverage.sh > $OUT/suite_coverage.log 2>&1
 grep -v "at::native\|__amd_rocclr\|^ *[0-9]* *$" gpurun_out/gpu_suite_kernels.txt > $OUT/gpu_suite_kernels.txt
-python3 profiles/tools/lat_sweep.py > $OUT/lat_sweep.txt 2>&1
+python3 profiles/tools/lat_sweep.py rodent 250 40 128 256 500 700 1000 1500 2000 3000 > $OUT/lat_sweep.txt 2>&1
 python3 profiles/tools/lat_sweep.py fly 100 40 256 500 1000 2000 > $OUT/lat_sweep_fly.txt 2>&1
 python3 profiles/tools/lat_sweep.py mouse 20 40 256 500 1000 > $OUT/lat_sweep_mouse.txt 2>&1
 echo done
