@@ -194,9 +194,6 @@ def run_fit_mode(args, rank, local_rank, world, dist):
             "parallelism": f"clips sharded over {world} GPU(s); offset phase: one all-reduce of {3 * fs.tables.nsite + 2} floats per "
                            f"calibration iteration ({n_pass - 1} per fit)",
             "collective_backend": (dist.get_backend() if dist else None), "collective_world_size": world,
-            # every rank's share and what it ran (a SCALE record can be diagnosed from the line alone), and the rate the committed
-            # single-GPU table predicts for this job (profiles/single_gpu_rates.json)
-            "per_rank": per_rank, "predicted_value": predicted_value(args.model, shape, world) if args.solver == "pg" else None,
             "mean_offset_error_mm_vs_generating_offsets": d_off,
         },
     }

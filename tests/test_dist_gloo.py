@@ -306,10 +306,11 @@ def test_bench_strong_and_weak_frame_accounting_two_ranks():
             if r["model"] == "rodent"}
     assert res[0]["cfg3"]["predicted"] == res[1]["cfg3"]["predicted"] == pytest.approx(2 * rows[(250, 2000)])
     assert res[0]["weak"]["predicted"] == pytest.approx(2 * rows[(1, 10000)])
-    lo_, hi_ = rows[(250, 500)], rows[(250, 1000)]
-    assert 2 * lo_ * 400 / 500 < res[0]["run"]["predicted"] * 1.0001 and res[0]["run"]["predicted"] <= 2 * lo_  # 400 clips per rank: below the 500-chain row
-    assert 501 * 250 / (res[0]["odd"]["predicted"] and 1001 * 250 / res[0]["odd"]["predicted"]) == pytest.approx(
-        np.exp(np.interp(np.log(501), np.log([500, 1000]), np.log([lo_, hi_]))), rel=1e-6)
+    ch = sorted(c for (f, c) in rows if f == 250)
+    rate = lambda n: float(np.exp(np.interp(np.log(n), np.log(ch), np.log([rows[(250, c)] for c in ch]))))  # log-linear between the rows
+    assert res[0]["run"]["predicted"] == pytest.approx(2 * rate(400), rel=1e-6)  # 400 clips per rank
+    # the odd job: the slowest rank has 501 of the 1 001 clips -> the job's frames over that rank's predicted time
+    assert res[0]["odd"]["predicted"] == pytest.approx(1001 * 250 / (501 * 250 / rate(501)), rel=1e-6)
     assert bench.predicted_value("rodent", dict(res[0]["cfg3"], F=7), 2) is None
     # the JSON line carries the mode it ran in
     src = (ROOT / "bench.py").read_text()
