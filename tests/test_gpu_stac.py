@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from helpers import oracle_fit_offsets as _oracle_fit_offsets
 
 pytestmark = pytest.mark.gpu
@@ -342,3 +342,32 @@ def test_fit_and_ik_two_ranks_over_rccl(tmp_path, rodent_setup, rodent_cfg, rode
     assert r0["qpos"].shape == (12, 74) and r1["qpos"].shape == (6, 74) and r0["ik_qpos"].shape == (12, 74)
     assert np.abs(r0["offsets"] - one.offsets).max() < 1e-5
     np.testing.assert_array_equal(r0["qpos"][6:], r1["qpos"])
+
+
+@pytest.mark.parametrize("args", [
+    ["--steps", "1", "--warmup", "0", "--frames", "500", "--no-cpu-baseline", "--no-extras"],
+    ["--steps", "1", "--warmup", "0", "--frames", "500", "--frames-per-clip", "250", "--no-cpu-baseline", "--no-extras"],
+    ["--steps", "1", "--warmup", "0", "--frames", "500", "--frames-per-clip", "250", "--scaling", "strong", "--no-cpu-baseline"],
+    ["--mode", "fit", "--steps", "1", "--warmup", "0", "--frames", "60", "--frames-per-clip", "10"],
+    ["--mode", "run", "--steps", "1", "--warmup", "0", "--frames", "500", "--frames-per-clip", "250"],
+    ["--solver", "lm", "--steps", "1", "--warmup", "0", "--frames", "200", "--no-cpu-baseline"],
+    ["--model", "fly", "--steps", "1", "--warmup", "0", "--frames", "200", "--no-cpu-baseline", "--no-extras"],
+], ids=["ik", "clips", "strong", "fit", "run", "lm", "fly"])
+def test_every_bench_mode_prints_its_line(args):
+    """Round 6 (a fit-mode line once named a field of the default mode and only failed on the GPU box, inside the round's collection):
+    every mode of bench.py runs at a small size as its own process and prints ONE JSON line with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
+    if "--mode" not in args:
+        assert d["roofline"]["frac"] > 0 and d["config"]["per_rank"][0]["clips"] > 0
+        assert ("predicted_value" in d["config"])

@@ -27,6 +27,18 @@ run $NS leanwide X=1
 for sw in STAC_HIP_SPEC=0 "STAC_HIP_SPEC=1 STAC_HIP_SPECG=32" STAC_HIP_NOFAST=1; do
   run $NB leanwide $sw
 done
+# round 6: trees of the lean kind WITH oriented bodies (the fruit fly's kind: one more product of the quaternion pass each), and the
+# switch that moves ranges between the by-component and the whole-range sums
+run $((2*NS)) leanbq X=1
+for sw in STAC_HIP_SPEC=0 STAC_HIP_NOFAST=1 STAC_HIP_NOPRUNE=1 STAC_HIP_RSPLIT=0 STAC_HIP_RSPLIT=8 "STAC_HIP_QUEUE=8 STAC_HIP_SPEC=0" \
+          "STAC_HIP_HANDOFF=8 STAC_HIP_SPEC=0" "STAC_HIP_SPEC=1 STAC_HIP_SPECG=16" "STAC_HIP_SPEC=1 STAC_HIP_SPECG=16 STAC_HIP_SPECR=8" \
+          "STAC_HIP_SPEC=1 STAC_HIP_SPECG=32" STAC_HIP_NOFK3BQ=1; do
+  run $NS leanbq $sw
+done
+run $NB leanwidebq X=1
+for sw in STAC_HIP_RSPLIT=0 STAC_HIP_RSPLIT=8; do
+  run $NS lean $sw
+done
 echo "== LM" >> $out
 timeout 900 python tests/fuzz_lm_random_models.py $NB 2>&1 | grep -v amdgpu.ids | tail -2 >> $out
 cat $out
