@@ -600,6 +600,32 @@ def test_npz_stand_in_is_written_by_parallel_deflate_and_read_by_numpy(tmp_path,
         assert f["qvel"].shape == (0,) and bytes(f["config"]) == b"a: 1\n" and f["kp_names"].tolist() == [b"k1", b"k2"]
 
 
+def test_crc32_of_a_member_from_its_blocks_and_the_writer_threads(monkeypatch):
+    """Round 6: every deflate block of the .npz stand-in carries its own CRC-32 and a member's is combined from them (a GF(2) shift
+    matrix per block length, cached): equal to zlib's CRC of the whole; the ranks of a node divide its cores among themselves; the
+    job window hands results back in order with a bounded number in flight."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    from stac_mjx_amd import io
+
+    rng = np.random.default_rng(5)
+    for n1, n2 in [(0, 5), (5, 0), (1, 1), (1000, 3), (12345, 1 << 16), (1 << 16, 70001), (3, 1 << 16)]:
+        a, b = rng.bytes(n1), rng.bytes(n2)
+        assert io._crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b), (n1, n2)
+    blocks = [rng.bytes(n) for n in (4096, 4096, 4096, 17)]
+    crc = zlib.crc32(blocks[0])
+    for blk in blocks[1:]:
+        crc = io._crc32_combine(crc, zlib.crc32(blk), len(blk))
+    assert crc == zlib.crc32(b"".join(blocks)) and 4096 in io._CRC_SHIFT
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    n8 = io._n_threads()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert 1 <= n8 <= max(io._n_threads() // 8, 1) and io._n_threads() <= 64
+    with ThreadPoolExecutor(4) as pool:
+        assert list(io._map_window(pool, lambda i: i * i, range(50), window=3)) == [i * i for i in range(50)]
+
+
 # ---- library loading guards and the bench launcher (no GPU needed) -------------------------------------------------------
 def test_load_library_refuses_a_stale_or_wrong_abi_library(monkeypatch):
     """The .so is git-ignored and travels apart from the sources: a library built from other sources, or one that
