@@ -377,13 +377,21 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    # Test hooks (tests/test_gpu_stac.py: the N > 1 code path of this script on a ONE-GPU box): STAC_BENCH_SHARE_GPU=1 puts every rank on
+    # cuda:0, STAC_BENCH_BACKEND=gloo carries the barrier / reductions (RCCL refuses two ranks on one device).  Never set by the driver.
+    backend = os.environ.get("STAC_BENCH_BACKEND", "nccl")
+    if os.environ.get("STAC_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run: RCCL barrier + max-over-ranks timing
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     if args.mode in ("fit", "run"):
         (run_fit_mode if args.mode == "fit" else run_run_mode)(args, rank, local_rank, world, dist)

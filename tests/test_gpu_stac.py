@@ -371,3 +371,59 @@ def test_every_bench_mode_prints_its_line(args):
     if "--mode" not in args:
         assert d["roofline"]["frac"] > 0 and d["config"]["per_rank"][0]["clips"] > 0
         assert ("predicted_value" in d["config"])
+
+
+@pytest.mark.parametrize("args,clips", [
+    (["--frames", "400"], [400, 400]),
+    (["--scaling", "strong", "--frames", "1000", "--frames-per-clip", "250"], [2, 2]),
+    (["--scaling", "strong", "--frames", "250", "--frames-per-clip", "250"], [1, 0]),
+], ids=["weak", "strong", "more-ranks-than-clips"])
+def test_bench_two_ranks_on_one_gpu(args, clips):
+    """The N > 1 path of bench.py -- what the driver runs on an 8-GPU node -- with two ranks on THIS box's one GPU (test hooks:
+    every rank on cuda:0, gloo for the barrier and the reductions): the timing barrier, the max over ranks, `config.per_rank` (one
+    all_gather_object), the offset-phase exchange with bitwise-equal offsets, a rank without clips."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, STAC_BENCH_BACKEND="gloo", STAC_BENCH_SHARE_GPU="1")
+    port = 29800 + int(torch.randint(0, 150, (1,)).item())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["collective_backend"] == "gloo"
+    pr = d["config"]["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and [p["clips"] for p in pr] == clips
+    assert d["config"]["frames_total"] == sum(p["frames"] for p in pr)
+    ex = d["config"]["offset_phase_exchange"]
+    assert ex["world_size"] == 2 and ex["offsets_bitwise_equal_across_ranks"] is True and ex["n_floats"] == 71
+    assert d["scaling"] == ("strong" if "--scaling" in args else "weak")
+
+
+@pytest.mark.parametrize("args", [["--mode", "fit", "--frames", "60", "--frames-per-clip", "10"],
+                                  ["--mode", "run", "--frames", "500", "--frames-per-clip", "250"]], ids=["fit", "run"])
+def test_bench_fit_and_run_modes_two_ranks_on_one_gpu(args):
+    """`--mode fit` (clips sharded, the 71-float all-reduce per calibration iteration) and `--mode run` (`Stac.ik_only` sharding one
+    global dataset itself) with two ranks on one GPU (same hooks): one line, whole-job accounting."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, STAC_BENCH_BACKEND="gloo", STAC_BENCH_SHARE_GPU="1")
+    port = 29950 + int(torch.randint(0, 40, (1,)).item())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    if args[1] == "fit":
+        assert d["config"]["collective_backend"] == "gloo" and d["config"]["collective_world_size"] == 2
